@@ -1,0 +1,102 @@
+"""ctypes binding of libxps.so (include/xps.h).  The product path has NO fallback: if
+the library is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libxps.so')
+HEADER_PATH = os.path.join(_PKG, '..', 'include', 'xps.h')
+
+_lib = None
+
+
+class RowMap(C.Structure):
+    """xps_rowmap: row i lives at (i // rpg) * gs + (i % rpg) * ld."""
+    _fields_ = [('gs', C.c_int64), ('ld', C.c_int64), ('rpg', C.c_int32), ('pad_', C.c_int32)]
+
+
+def rowmap(ld, rpg=1 << 30, gs=0):
+    return RowMap(int(gs), int(ld), int(rpg), 0)
+
+
+class XpsError(RuntimeError):
+    pass
+
+
+_vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_rm = C.POINTER(RowMap)
+
+# name -> (restype, argtypes); must list every function declared in include/xps.h
+SIGNATURES = {
+    'xps_last_error': (C.c_char_p, []),
+    'xps_abi_version': (_i, []),
+    'xps_gemm_nt_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),
+    'xps_gemm_nn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp]),
+    'xps_gemm_tn_f32_workspace': (_sz, [_i, _i, _i]),
+    'xps_gemm_tn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'xps_colsum_f32_workspace': (_sz, [_i, _i]),
+    'xps_colsum_f32': (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    'xps_gru_seq_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'xps_gru_seq_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'xps_transpose_f32': (_i, [_vp, _vp, _i, _i, _vp]),
+    'xps_bn_finalize_f32': (_i, [_vp, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp]),
+    'xps_bn_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
+    'xps_bn_apply_eval_f32': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    'xps_bn_bwd_workspace': (_sz, [_i64, _i]),
+    'xps_bn_bwd_reduce_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i64, _i, _vp, _sz, _vp]),
+    'xps_bn_bwd_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _d, _vp, _i64, _i, _vp]),
+    'xps_gather_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'xps_scatter_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'xps_next_token': (_i, [_vp, _i, _vp, _i64, _vp, _vp, _i, _vp]),
+    'xps_mask_scale_f32': (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
+    'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'xps_cross_entropy_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    'xps_cross_entropy_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    'xps_sumsq_f32_workspace': (_sz, [_i64]),
+    'xps_sumsq_f32': (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    'xps_adamw_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    'xps_cnd_avg_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    'xps_cnd_avg_f64': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    'xps_colsum_f64_workspace': (_sz, [_i64, _i]),
+    'xps_colsum_f64': (_i, [_vp, _i, _i64, _i64, _i, _vp, _vp, _sz, _vp]),
+    'xps_xcov_f64_workspace': (_sz, [_i64, _i, _i]),
+    'xps_xcov_f64': (_i, [_vp, _i, _i64, _vp, _vp, _i, _i64, _vp, _vp, _i64, _i64, _i, _i, _vp, _sz, _vp]),
+    'xps_jacobi_f64_workspace': (_sz, [_i]),
+    'xps_jacobi_sweeps_f64': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'xps_apply_f64': (_i, [_vp, _i, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i, _i, _vp]),
+    'xps_dgemm_small': (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp]),
+}
+
+
+def header_functions(path=HEADER_PATH):
+    """Names of all functions declared in include/xps.h."""
+    with open(path) as f:
+        src = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(xps_[a-z0-9_]+)\s*\(', src)))
+
+
+def lib():
+    """Load libxps.so once.  Raises if it is not built — there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XpsError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(hipcc --offload-arch=gfx950).  The HIP path has no CPU fallback.')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().xps_last_error()
+        raise XpsError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero code."""
+    check(getattr(lib(), name)(*args), name)

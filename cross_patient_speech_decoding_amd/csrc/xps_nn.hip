@@ -1,0 +1,495 @@
+// HBM-bound passes around the MFMA kernels: column reductions (bias gradients,
+// BatchNorm statistics), fused BatchNorm(+ReLU)(+dropout) forward/backward, decoder
+// glue (row gather / scatter, next-token select), cross-entropy, and the fused
+// clip-by-global-norm + AdamW update over the flat parameter buffer.
+// All reductions are two-stage and deterministic (no float atomics).
+#include "xps_common.h"
+
+namespace {
+
+constexpr int RED_ROWS = 256;   // rows folded by one block of the first reduction stage
+
+// stage 1: block (bx, by) sums rows [by*RED_ROWS, ...) of columns [bx*64, bx*64+64)
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, long long ldx, int rows, int cols,
+                                                     float* __restrict__ part, float* __restrict__ part_sq) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * RED_ROWS;
+    const int r1 = min(rows, r0 + RED_ROWS);
+    float a = 0.f, a2 = 0.f;
+    if (c < cols)
+        for (int r = r0 + rq; r < r1; r += 4) {
+            float v = X[(long long)r * ldx + c];
+            a += v;
+            a2 += v * v;
+        }
+    s1[rq][threadIdx.x & 63] = a;
+    s2[rq][threadIdx.x & 63] = a2;
+    __syncthreads();
+    if (rq == 0 && c < cols) {
+        const int l = threadIdx.x;
+        part[(long long)blockIdx.y * cols + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+        if (part_sq) part_sq[(long long)blockIdx.y * cols + c] = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
+    }
+}
+
+__global__ void colsum_stage2(const float* __restrict__ part, const float* __restrict__ part_sq, int nparts, int cols,
+                              float* __restrict__ out, float* __restrict__ out_sq, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f, a2 = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        a += part[(long long)i * cols + c];
+        if (part_sq) a2 += part_sq[(long long)i * cols + c];
+    }
+    if (accumulate) {
+        a += out[c];
+        if (out_sq) a2 += out_sq[c];
+    }
+    out[c] = a;
+    if (out_sq) out_sq[c] = a2;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, double count, float* mean, float* rstd,
+                                   float* running_mean, float* running_var, float momentum, float eps, int F) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    const double m = (double)stats[c] / count;
+    double var = (double)stats[F + c] / count - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ mask, float scale, float* __restrict__ out,
+                                long long total, int F, int relu) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % F);
+        float v = (y[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        if (mask) v = v * mask[i] * scale;
+        out[i] = v;
+    }
+}
+
+__global__ void bn_apply_eval_kernel(const float* __restrict__ y, const float* __restrict__ rm, const float* __restrict__ rv,
+                                     float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* __restrict__ out, long long total, int F, int relu) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % F);
+        float v = (y[i] - rm[c]) * (1.0f / sqrtf(rv[c] + eps)) * gamma[c] + beta[c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        out[i] = v;
+    }
+}
+
+// g = dout * mask*scale * relu'(out);  part[by][c] = sum g ; part[by][F + c] = sum g * xhat
+__global__ __launch_bounds__(256) void bn_bwd_stage1(const float* __restrict__ dout, const float* __restrict__ out,
+                                                     const float* __restrict__ y, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ mask,
+                                                     float scale, int relu, long long rows, int F, float* __restrict__ part) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * RED_ROWS;
+    const long long r1 = r0 + RED_ROWS < rows ? r0 + RED_ROWS : rows;
+    float a = 0.f, a2 = 0.f;
+    if (c < F) {
+        const float m = mean[c], rs = rstd[c];
+        for (long long r = r0 + rq; r < r1; r += 4) {
+            const long long i = r * F + c;
+            float g = dout[i];
+            if (mask) g = g * mask[i] * scale;
+            if (relu && !(out[i] > 0.f)) g = 0.f;
+            a += g;
+            a2 += g * ((y[i] - m) * rs);
+        }
+    }
+    s1[rq][threadIdx.x & 63] = a;
+    s2[rq][threadIdx.x & 63] = a2;
+    __syncthreads();
+    if (rq == 0 && c < F) {
+        const int l = threadIdx.x;
+        part[(long long)blockIdx.y * 2 * F + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+        part[(long long)blockIdx.y * 2 * F + F + c] = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ mask, float scale, int relu,
+                                    const float* __restrict__ sums, float inv_count, float* __restrict__ dy,
+                                    long long total, int F) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % F);
+        float g = dout[i];
+        if (mask) g = g * mask[i] * scale;
+        if (relu && !(out[i] > 0.f)) g = 0.f;
+        const float xh = (y[i] - mean[c]) * rstd[c];
+        dy[i] = gamma[c] * rstd[c] * (g - sums[c] * inv_count - xh * sums[F + c] * inv_count);
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx, float* __restrict__ out,
+                                   int B, int cols, int n_rows) {
+    const long long total = (long long)B * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / cols), c = (int)(i % cols);
+        long long r = idx[b];
+        r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+        out[i] = table[r * cols + c];
+    }
+}
+
+// one block per (table row, 64-column strip): ordered sum over the batch
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dout, const long long* __restrict__ idx,
+                                                           float* __restrict__ dtable, int B, int cols, int accumulate) {
+    __shared__ float s[4][64];
+    const int row = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < cols)
+        for (int b = q; b < B; b += 4)
+            if (idx[b] == row) a += dout[(long long)b * cols + c];
+    s[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        const int l = threadIdx.x;
+        float v = (s[0][l] + s[1][l]) + (s[2][l] + s[3][l]);
+        float* p = dtable + (long long)row * cols + c;
+        *p = accumulate ? *p + v : v;
+    }
+}
+
+__global__ void next_token_kernel(const float* __restrict__ logits, int C, const long long* __restrict__ teacher,
+                                  long long tstride, const int* __restrict__ use_teacher, long long* __restrict__ next, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (use_teacher && teacher && use_teacher[0]) {
+        next[b] = teacher[(long long)b * tstride];
+        return;
+    }
+    const float* p = logits + (long long)b * C;
+    float best = p[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c)
+        if (p[c] > best) { best = p[c]; bi = c; }
+    next[b] = bi;
+}
+
+__global__ void mask_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float scale,
+                                  float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i] * mask[i] * scale;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+__global__ void ce_rows_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                               float* __restrict__ row_loss, long long rows, int C) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = logits + r * C;
+    float mx = p[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(p[c] - mx);
+    row_loss[r] = (logf(s) + mx) - p[target[r]];
+}
+
+// single block: ordered tree over row losses -> mean
+__global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__ row_loss, long long rows, float* loss) {
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (long long i = threadIdx.x; i < rows; i += 1024) a += (double)row_loss[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(sh[0] / (double)rows);
+}
+
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                              const float* __restrict__ gout, float* __restrict__ dlogits, long long rows, int C) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = logits + r * C;
+    float mx = p[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(p[c] - mx);
+    const float g = gout[0] / (float)rows, inv = 1.f / s;
+    const long long tg = target[r];
+    for (int c = 0; c < C; ++c) dlogits[r * C + c] = g * (expf(p[c] - mx) * inv - (c == tg ? 1.f : 0.f));
+}
+
+constexpr int SS_CHUNK = 8192;
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, long long n, double* __restrict__ part) {
+    __shared__ double sh[256];
+    const long long i0 = (long long)blockIdx.x * SS_CHUNK;
+    const long long i1 = i0 + SS_CHUNK < n ? i0 + SS_CHUNK : n;
+    double a = 0.0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) { const double v = g[i]; a += v * v; }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void sumsq_stage2(const double* __restrict__ part, int nparts, float* sumsq) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sumsq[0] = (float)sh[0];
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, const float* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2_sqrt) {
+    float coef = 1.f;
+    if (max_norm > 0.f && sumsq) {
+        const float c = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        g[i] = gi;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+inline int ew_grid(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" size_t xps_colsum_f32_workspace(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 16;
+    return (size_t)2 * cdiv(rows, RED_ROWS) * cols * sizeof(float) + 16;
+}
+
+extern "C" int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, float* out_sq,
+                              int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(X && out && rows >= 0 && cols >= 1, "bad argument");
+    if (workspace_bytes < xps_colsum_f32_workspace(rows, cols) || !workspace) {
+        xps_set_error("xps_colsum_f32: workspace too small");
+        return XPS_E_WORKSPACE;
+    }
+    const int nparts = rows > 0 ? cdiv(rows, RED_ROWS) : 0;
+    float* part = (float*)workspace;
+    float* part_sq = out_sq ? part + (size_t)nparts * cols : nullptr;
+    if (nparts > 0) {
+        hipLaunchKernelGGL(colsum_stage1, dim3(cdiv(cols, 64), nparts), dim3(256), 0, (hipStream_t)stream,
+                           X, (long long)ldx, rows, cols, part, part_sq);
+        XPS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, part_sq, nparts, cols, out, out_sq, accumulate);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_bn_finalize_f32(const float* stats, double count, float* mean, float* rstd,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   int F, void* stream) {
+    XPS_CHECK_ARG(stats && mean && rstd && F >= 1 && count >= 1, "bad argument");
+    XPS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(F, 256)), dim3(256), 0, (hipStream_t)stream,
+                       stats, count, mean, rstd, running_mean, running_var, momentum, eps, F);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_bn_apply_f32(const float* y, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const float* drop_mask, float drop_scale, float* out,
+                                int64_t rows, int F, int relu, void* stream) {
+    XPS_CHECK_ARG(y && mean && rstd && gamma && beta && out && rows >= 0 && F >= 1, "bad argument");
+    const long long total = (long long)rows * F;
+    if (total == 0) return XPS_OK;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       y, mean, rstd, gamma, beta, drop_mask, drop_scale, out, total, F, relu);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_bn_apply_eval_f32(const float* y, const float* running_mean, const float* running_var, float eps,
+                                     const float* gamma, const float* beta, float* out, int64_t rows, int F,
+                                     int relu, void* stream) {
+    XPS_CHECK_ARG(y && running_mean && running_var && gamma && beta && out && rows >= 0 && F >= 1, "bad argument");
+    const long long total = (long long)rows * F;
+    if (total == 0) return XPS_OK;
+    hipLaunchKernelGGL(bn_apply_eval_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       y, running_mean, running_var, eps, gamma, beta, out, total, F, relu);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" size_t xps_bn_bwd_workspace(int64_t rows, int F) {
+    if (rows <= 0 || F <= 0) return 16;
+    return (size_t)cdiv(rows, RED_ROWS) * 2 * F * sizeof(float) + 16;
+}
+
+extern "C" int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const float* y, const float* mean,
+                                     const float* rstd, const float* drop_mask, float drop_scale, int relu,
+                                     float* sums, int64_t rows, int F, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    XPS_CHECK_ARG(dout && y && mean && rstd && sums && rows >= 1 && F >= 1, "bad argument");
+    XPS_CHECK_ARG(!relu || out, "relu backward needs the forward output");
+    if (workspace_bytes < xps_bn_bwd_workspace(rows, F) || !workspace) {
+        xps_set_error("xps_bn_bwd_reduce_f32: workspace too small");
+        return XPS_E_WORKSPACE;
+    }
+    const int nparts = cdiv(rows, RED_ROWS);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(bn_bwd_stage1, dim3(cdiv(F, 64), nparts), dim3(256), 0, (hipStream_t)stream,
+                       dout, out, y, mean, rstd, drop_mask, drop_scale, relu, (long long)rows, F, part);
+    XPS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(2 * F, 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, (const float*)nullptr, nparts, 2 * F, sums, (float*)nullptr, 0);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_bn_bwd_apply_f32(const float* dout, const float* out, const float* y, const float* mean,
+                                    const float* rstd, const float* gamma, const float* drop_mask, float drop_scale,
+                                    int relu, const float* sums, double count, float* dy, int64_t rows, int F,
+                                    void* stream) {
+    XPS_CHECK_ARG(dout && y && mean && rstd && gamma && sums && dy && rows >= 0 && F >= 1 && count >= 1, "bad argument");
+    XPS_CHECK_ARG(!relu || out, "relu backward needs the forward output");
+    const long long total = (long long)rows * F;
+    if (total == 0) return XPS_OK;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       dout, out, y, mean, rstd, gamma, drop_mask, drop_scale, relu, sums, (float)(1.0 / count), dy,
+                       total, F);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_gather_rows_f32(const float* table, const int64_t* idx, float* out, int B, int cols, int n_rows,
+                                   void* stream) {
+    XPS_CHECK_ARG(table && idx && out && B >= 0 && cols >= 1 && n_rows >= 1, "bad argument");
+    if (B == 0) return XPS_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid((long long)B * cols)), dim3(256), 0, (hipStream_t)stream,
+                       table, (const long long*)idx, out, B, cols, n_rows);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float* dtable, int B, int cols, int n_rows,
+                                    int accumulate, void* stream) {
+    XPS_CHECK_ARG(dout && idx && dtable && B >= 0 && cols >= 1 && n_rows >= 1, "bad argument");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(cols, 64), n_rows), dim3(256), 0, (hipStream_t)stream,
+                       dout, (const long long*)idx, dtable, B, cols, accumulate);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_next_token(const float* logits, int n_classes, const int64_t* teacher, int64_t teacher_stride,
+                              const int32_t* use_teacher, int64_t* next, int B, void* stream) {
+    XPS_CHECK_ARG(logits && next && n_classes >= 1 && B >= 0, "bad argument");
+    if (B == 0) return XPS_OK;
+    hipLaunchKernelGGL(next_token_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, n_classes, (const long long*)teacher, (long long)teacher_stride, (const int*)use_teacher,
+                       (long long*)next, B);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_mask_scale_f32(const float* x, const float* mask, float scale, float* out, int64_t n, void* stream) {
+    XPS_CHECK_ARG(x && mask && out && n >= 0, "bad argument");
+    if (n == 0) return XPS_OK;
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, out,
+                       (long long)n);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    XPS_CHECK_ARG(a && b && out && n >= 0, "bad argument");
+    if (n == 0) return XPS_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float* row_loss, float* loss,
+                                         int64_t rows, int n_classes, void* stream) {
+    XPS_CHECK_ARG(logits && target && row_loss && loss && rows >= 1 && n_classes >= 1, "bad argument");
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, (const long long*)target, row_loss, (long long)rows, n_classes);
+    XPS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, (long long)rows, loss);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* gout, float* dlogits,
+                                         int64_t rows, int n_classes, void* stream) {
+    XPS_CHECK_ARG(logits && target && gout && dlogits && rows >= 1 && n_classes >= 1, "bad argument");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, (const long long*)target, gout, dlogits, (long long)rows, n_classes);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" size_t xps_sumsq_f32_workspace(int64_t n) {
+    return (size_t)(cdiv(n > 0 ? n : 1, SS_CHUNK)) * sizeof(double) + 16;
+}
+
+extern "C" int xps_sumsq_f32(const float* g, int64_t n, float* sumsq, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    XPS_CHECK_ARG(g && sumsq && n >= 0, "bad argument");
+    if (workspace_bytes < xps_sumsq_f32_workspace(n) || !workspace) {
+        xps_set_error("xps_sumsq_f32: workspace too small");
+        return XPS_E_WORKSPACE;
+    }
+    XPS_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "workspace must be 8-byte aligned");
+    const int nparts = n > 0 ? cdiv(n, SS_CHUNK) : 0;
+    if (nparts > 0) {
+        hipLaunchKernelGGL(sumsq_stage1, dim3(nparts), dim3(256), 0, (hipStream_t)stream, g, (long long)n, (double*)workspace);
+        XPS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nparts, sumsq);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    XPS_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "bad argument");
+    XPS_CHECK_ARG(max_norm <= 0.f || sumsq, "clipping needs the sum of squares");
+    if (n == 0) return XPS_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, sumsq,
+                       max_norm, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}

