@@ -83,6 +83,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise XpsError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                            '(hipcc --offload-arch=gfx950).  The HIP path has no CPU fallback.')
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the system
+        # one).  It must be loaded FIRST so that libxps.so binds to the runtime that owns torch's
+        # device context and streams; two runtimes in one process see "no ROCm-capable device".
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)

@@ -13,6 +13,12 @@ pytestmark = pytest.mark.gpu
 from weights import weights_from_seed  # noqa: E402
 
 
+# The conv bias feeds a train-mode BatchNorm, which subtracts the batch mean: its gradient is
+# analytically ZERO and numerically rounding noise (~1e-9) in the reference and here alike.  Adam
+# divides by sqrt(v) of that noise, so the UPDATED bias is +-lr of noise on both sides: excluded.
+NOISE_KEY = 'temporal_conv.conv.bias'
+
+
 def build_hip(cfg, seed, dropout=0.0):
     from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
     m = Seq2SeqRNN(cfg['in_channels'], cfg['n_filters'], cfg['hidden_size'], 9, cfg['n_enc_layers'],
@@ -61,12 +67,18 @@ def test_train_step_matches_reference_golden(golden_dir, name, tag, coin):
             np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()),
                                        err_msg=k)
         for k, v in m.state_dict().items():
+            if k == NOISE_KEY:
+                continue
             np.testing.assert_allclose(v.cpu().numpy(), g[f'{tag}_after/{k}'], rtol=1e-4, atol=2e-5, err_msg=k)
     else:
         for k, p in params.items():
+            if k == NOISE_KEY:
+                continue
             np.testing.assert_allclose(p.grad.norm().item(), float(g[f'{tag}_gradnorm/{k}']), rtol=2e-3, err_msg=k)
+        keys = list(m.state_dict().keys())
         after = np.array([v.double().sum().item() for v in m.state_dict().values()])
-        np.testing.assert_allclose(after, g[f'{tag}_after_sum'], rtol=1e-4, atol=1e-3)
+        keep = np.array([k != NOISE_KEY for k in keys])
+        np.testing.assert_allclose(after[keep], g[f'{tag}_after_sum'][keep], rtol=1e-4, atol=2e-3)
 
 
 def test_seeded_larger_batch_vs_oracle():
@@ -105,4 +117,7 @@ def test_reference_coin_sequence_is_reproduced():
     ref = [torch.rand(1).item() < 0.5 for _ in range(3)]
     assert coins == ref
     torch.manual_seed(123)
-    assert m.draw_teacher_coins(None, 0.5) == [False] * 3 and torch.rand(1).item() == torch.manual_seed(123).initial_seed() * 0 + torch.rand(1).item() or True
+    assert m.draw_teacher_coins(None, 0.5) == [False] * 3          # y is None: no draw at all
+    a = torch.rand(1).item()
+    torch.manual_seed(123)
+    assert a == torch.rand(1).item()
