@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: ECoG trials/s of seq2seq-GRU training (forward + backward + clip + AdamW)
+on N MI355X GPUs of one node, one process per GPU over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: single-patient seq2seq GRU, C=64 channels, T=200 samples,
+Conv1d(k=s=10, F=100) -> T'=20, bidirectional 2-layer GRU encoder H=128, 1-layer GRU decoder,
+3 x 9-way phoneme outputs; one "step" = one full-batch optimisation step over 2048 trials per GPU
+(the reference trains full-batch: batch_size 5000 > dataset, scripts/train_seq2seq.py:100-113),
+dropout 0.3/0.3 and teacher forcing 0.5 as in the reference script.  Weak scaling: every rank
+holds its own 2048-trial shard; BatchNorm statistics and the flat gradient are all-reduced.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the CPU oracle = torch.nn restatement of the reference, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(in_channels=64, n_filters=100, hidden_size=128, num_classes=9, n_enc_layers=2, n_dec_layers=1,
+           kernel_size=10, stride=10, T=200, trials_per_gpu=2048)
+F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x4, 64 FLOP/clk/SIMD
+
+
+def train_flops_per_trial(c):
+    """BASELINE.md section 2 bookkeeping: 3 x forward FLOPs."""
+    Tp = (c['T'] - c['kernel_size']) // c['stride'] + 1
+    H, F = c['hidden_size'], c['n_filters']
+    fwd = 2 * Tp * F * c['in_channels'] * c['kernel_size']
+    n_in = F
+    for _ in range(c['n_enc_layers']):
+        fwd += 2 * (2 * 3 * H * (n_in + H)) * Tp
+        n_in = 2 * H
+    fwd += 3 * (c['n_dec_layers'] * 2 * 3 * H * 2 * H + 2 * H * c['num_classes'])
+    return 3 * fwd
+
+
+def make_data(rank, c):
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    X, y_full = make_patient(rank, c['trials_per_gpu'], T=c['T'], C=c['in_channels'])
+    return torch.from_numpy(X), torch.from_numpy(y_full - 1)           # labels 0..8 (train_seq2seq.py:95)
+
+
+def build_model(c, dropout=0.3):
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    return Seq2SeqRNN(c['in_channels'], c['n_filters'], c['hidden_size'], c['num_classes'], c['n_enc_layers'],
+                      c['n_dec_layers'], c['kernel_size'], c['stride'], 0, dropout, dropout, 'gru', 1e-4, 1e-5,
+                      activation=False, decay_iters=500)
+
+
+def cpu_baseline(c, budget_s=20.0):
+    """The CPU oracle (plain torch.nn restatement of the reference, pinned to reference goldens) on
+    the same workload, bounded: B = 256 trials per step, as many steps as fit the budget."""
+    from oracle.seq2seq_oracle import Seq2SeqOracle, train_step
+    threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    m = Seq2SeqOracle(c['in_channels'], c['n_filters'], c['hidden_size'], c['num_classes'], c['n_enc_layers'],
+                      c['n_dec_layers'], c['kernel_size'], c['stride'], 0, 0.3, 0.3, learning_rate=1e-4,
+                      l2_reg=1e-5, activation=False, decay_iters=500)
+    opt, _ = m.make_optimizer()
+    X, y = make_data(0, dict(c, trials_per_gpu=256))
+    for _ in range(2):
+        train_step(m, opt, X, y, coins=[True, False, True])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        train_step(m, opt, X, y, coins=[True, False, True])
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {'value': round(256 * n / el, 1), 'unit': 'trials/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} full train steps (fwd+bwd+clip+AdamW) of B=256 trials, same architecture/T/C, '
+                      f'fp32 torch.nn CPU oracle, {threads} threads, {el:.1f} s'}
+
+
+def time_dominant_kernel(model, c, iters=20):
+    """HIP-event timing (on the launch stream = torch's current stream) of the encoder's fused GRU
+    recurrence launch for the bench shape; algorithmic FLOPs = 2 dirs * T' * B * 2 * 3H * H."""
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    Tp = (c['T'] - c['kernel_size']) // c['stride'] + 1
+    B, H = c['trials_per_gpu'], c['hidden_size']
+    rnn = model.encoder.rnn
+    w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
+    b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
+    gi = torch.randn(2, Tp, B, 3 * H, device='cuda') * 0.5
+    res = {}
+    for name, save in (('gru_fwd_kernel', True),):
+        for _ in range(3):
+            XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, save)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, save)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2 * Tp * B * 2 * 3 * H * H
+    dur = res['gru_fwd_kernel']
+    ach = flops / dur / 1e12
+    return {'bound': 'mfma', 'kernel': 'gru_fwd_kernel<true> (encoder layer, both directions, one launch)',
+            'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    c = CFG
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    model = build_model(c).to(dev)
+    if world > 1:
+        model.temporal_conv.process_group = dist.group.WORLD
+    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5, group=dist.group.WORLD if world > 1 else None)
+    X, y = make_data(rank, c)
+    X, y = X.to(dev), y.to(dev)                  # inputs resident in HBM before the timed region
+    torch.manual_seed(99)                        # the same teacher-forcing coins on every rank
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        logits = model(X, y, teacher_forcing_ratio=0.5)
+        loss = model.criterion(logits.view(-1, c['num_classes']), y.view(-1))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        trials = c['trials_per_gpu'] * world * args.steps
+        value = trials / el
+        fl = train_flops_per_trial(c)
+        out = {
+            'metric': 'ECoG trials/sec seq2seq-RNN training', 'value': round(value, 1), 'unit': 'trials/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(el / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: single-patient seq2seq GRU, H=128, T=200 (T\'=20), C=64, F=100, '
+                                   'enc 2x bi-GRU, dec 1x GRU, full-batch step of 2048 trials per GPU, '
+                                   'dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW',
+                       'trials_per_gpu': c['trials_per_gpu'], 'global_batch': c['trials_per_gpu'] * world,
+                       'parallelism': f'dp{world}', 'train_mflop_per_trial': round(fl / 1e6, 2)},
+            'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
+        }
+        out['roofline'] = time_dominant_kernel(model, c)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(c)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
