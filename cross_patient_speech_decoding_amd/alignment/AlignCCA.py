@@ -1,0 +1,176 @@
+"""CCA alignment of two patients' latent dynamics on the MI355X — drop-in surface of the
+reference's ``alignment/AlignCCA.py`` (AlignCCA :11-119, reshape_latent_dynamics :122,
+extract_latent_dynamics_by_class :156, extract_latent_dynamics_by_trial_subselect :186,
+shared_trial_subselect :205, CCA_align :235).
+
+Same constructor, ``fit(X_a, X_b, y_a, y_b)`` / ``transform(X)``, numpy float64 attributes
+``M_a``, ``M_b``, ``canon_corrs`` and error strings.  Arithmetic (HIP, libxps.so):
+
+  condition means      xps_cnd_avg_*   (np.mean semantics, bit for bit)
+  covariances          xps_xcov_f64    C_aa, C_bb, C_ab centred, f64 MFMA
+  whitening + SVD      xps_jacobi_*    C_aa = V L V^T  ->  W_a = V L^-1/2 (rank-truncated);
+                                       K = W_a^T C_ab W_b = U S V^T
+  directions           M_a = W_a U[:, :d], M_b = W_b V[:, :d], d = min(rank_a, rank_b)
+  transform            xps_apply_f64   X @ (M_b pinv(M_a))
+
+This is the reference's QR+SVD CCA (:269-277) written on the covariance side: with L^T = Q R,
+R^-1 = W_a O for an orthogonal O, so pinv(R_a) U_ref = W_a U; M_a / M_b agree with the reference
+up to a common sign per canonical pair, and ``transform`` outputs agree exactly (signs cancel).
+"""
+import numpy as np
+
+from . import _linalg as LA
+from .alignment_utils import _cnd_avg_device, label2str
+
+
+class AlignCCA:
+    """CCA-based alignment of two neural datasets into a shared latent space.
+
+    Attributes:
+        type (str): 'class' (condition averages) or 'trial' (matched random trials).
+        return_space (str): 'b_to_a', 'a_to_b' or 'shared'.
+        M_a, M_b (ndarray float64): manifold directions (set by fit).
+        canon_corrs (ndarray float64): canonical correlations (set by fit).
+    """
+
+    def __init__(self, type='class', return_space='b_to_a'):
+        self.type = type
+        self.return_space = return_space
+
+    # sklearn-style parameter access so the class can sit inside clone()-able wrappers
+    def get_params(self, deep=True):
+        return {'type': self.type, 'return_space': self.return_space}
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            setattr(self, k, v)
+        return self
+
+    def fit(self, X_a, X_b, y_a, y_b):
+        L_a, L_b = _latent_dynamics_device(X_a, X_b, y_a, y_b, self.type)
+        M_a, M_b, S = _cca_device(L_a, L_b)
+        self.M_a, self.M_b, self.canon_corrs = M_a, M_b, S
+        self._maps = {}
+        return None
+
+    def transform(self, X):
+        if not self._check_fit():
+            raise RuntimeError('Must call fit() before transforming data.')
+        if self.return_space in ['b_to_a', 'a_to_b']:
+            return self._transform_single(X)
+        return self._transform_shared(X)
+
+    def _map(self, key):
+        # M_b pinv(M_a) (or the reverse) is formed once per fit, on the device
+        maps = self.__dict__.setdefault('_maps', {})
+        if key not in maps:
+            src, dst = (self.M_b, self.M_a) if key == 'b_to_a' else (self.M_a, self.M_b)
+            maps[key] = LA.dgemm(LA.to_device(src), LA.to_device(LA.pinv_small(dst)))
+        return maps[key]
+
+    def _transform_single(self, X):
+        key = 'b_to_a' if self.return_space == 'b_to_a' else 'a_to_b'
+        return _apply_host(X, self._map(key))
+
+    def _transform_shared(self, X):
+        return _apply_host(X[0], LA.to_device(self.M_a)), _apply_host(X[1], LA.to_device(self.M_b))
+
+    def _check_fit(self):
+        try:
+            self.M_a
+            self.M_b
+        except AttributeError:
+            return False
+        return True
+
+
+def _apply_host(X, W_dev):
+    """X (..., d_in) ndarray or tensor -> float64 ndarray (..., d_out) = X @ W on the device."""
+    return LA.apply(LA.to_device(X), W_dev).cpu().numpy()
+
+
+def _latent_dynamics_device(X_a, X_b, y_a, y_b, type='class'):
+    if type == 'class':
+        k_a, k_b = label2str(y_a), label2str(y_b)
+        u_a, A = _cnd_avg_device(X_a, k_a)
+        u_b, B = _cnd_avg_device(X_b, k_b)
+        _, i_a, i_b = np.intersect1d(u_a, u_b, assume_unique=True, return_indices=True)
+        A = A[LA.torch.from_numpy(i_a).to(A.device)]
+        B = B[LA.torch.from_numpy(i_b).to(B.device)]
+    elif type == 'trial':
+        A, B = extract_latent_dynamics_by_trial_subselect(X_a, X_b, y_a, y_b)
+        A, B = LA.to_device(A), LA.to_device(B)
+    else:
+        raise ValueError('type must be "class" or "trial".')
+    return A.reshape(-1, A.shape[-1]), B.reshape(-1, B.shape[-1])
+
+
+def _cca_device(La, Lb):
+    """La (n, d_a), Lb (n, d_b) device matrices (rows = samples) -> numpy M_a, M_b, S."""
+    n = La.shape[0]
+    m_a, m_b = LA.col_mean(La), LA.col_mean(Lb)
+    C_aa = LA.xcov(La, None, m_a)
+    C_bb = LA.xcov(Lb, None, m_b)
+    C_ab = LA.xcov(La, Lb, m_a, m_b)
+    w_a, V_a = LA.eigh_psd(C_aa)
+    w_b, V_b = LA.eigh_psd(C_bb)
+    r_a, r_b = LA.rank_from_gram_eigs(w_a, n), LA.rank_from_gram_eigs(w_b, n)
+    d = min(r_a, r_b)
+    W_a = LA.to_device(V_a[:, :r_a] / np.sqrt(w_a[:r_a]))
+    W_b = LA.to_device(V_b[:, :r_b] / np.sqrt(w_b[:r_b]))
+    K = LA.dgemm(LA.dgemm(W_a, C_ab, ta=True), W_b)
+    U, S, Vt = LA.svd(K)
+    M_a = LA.dgemm(W_a, LA.to_device(np.ascontiguousarray(U[:, :d]))).cpu().numpy()
+    M_b = LA.dgemm(W_b, LA.to_device(np.ascontiguousarray(Vt.T[:, :d]))).cpu().numpy()
+    S = S[:d].copy()
+    S[S < 0] = 0
+    S[S >= 1] = 1
+    return M_a, M_b, S
+
+
+def reshape_latent_dynamics(X_a, X_b, y_a, y_b, type='class'):
+    """Shared-condition latent dynamics of both datasets with time folded into rows,
+    (n_shared * T, d_a), (n_shared * T, d_b) float64."""
+    L_a, L_b = _latent_dynamics_device(X_a, X_b, y_a, y_b, type)
+    return L_a.cpu().numpy(), L_b.cpu().numpy()
+
+
+def extract_latent_dynamics_by_class(X_a, X_b, y_a, y_b):
+    k_a, k_b = label2str(y_a), label2str(y_b)
+    u_a, A = _cnd_avg_device(X_a, k_a)
+    u_b, B = _cnd_avg_device(X_b, k_b)
+    _, i_a, i_b = np.intersect1d(u_a, u_b, assume_unique=True, return_indices=True)
+    return A.cpu().numpy()[i_a], B.cpu().numpy()[i_b]
+
+
+def extract_latent_dynamics_by_trial_subselect(X_a, X_b, y_a, y_b):
+    y_a, y_b = label2str(y_a), label2str(y_b)
+    return shared_trial_subselect(X_a, X_b, y_a, y_b)
+
+
+def shared_trial_subselect(X_a, X_b, y_a, y_b):
+    """Equal numbers of randomly chosen trials per shared class (host indexing; the draws come
+    from numpy's global RNG exactly as in the reference, :225-226)."""
+    X_a, X_b = np.asarray(X_a), np.asarray(X_b)
+    L_a, L_b = [], []
+    for c in np.intersect1d(y_a, y_b):
+        curr_a = np.random.permutation(np.where(y_a == c)[0])
+        curr_b = np.random.permutation(np.where(y_b == c)[0])
+        k = min(curr_a.shape[0], curr_b.shape[0])
+        L_a.append(X_a[curr_a[:k]])
+        L_b.append(X_b[curr_b[:k]])
+    return np.vstack(L_a), np.vstack(L_b)
+
+
+def CCA_align(L_a, L_b):
+    """CCA between two (d, n_samples) latent matrices -> (M_a, M_b, S).
+
+    Like the reference (:259-260) the inputs are mean-centred IN PLACE along the sample axis when
+    they are float ndarrays; the means themselves come from the device reduction."""
+    A = LA.to_device(np.ascontiguousarray(np.asarray(L_a).T))
+    B = LA.to_device(np.ascontiguousarray(np.asarray(L_b).T))
+    if isinstance(L_a, np.ndarray) and np.issubdtype(L_a.dtype, np.floating):
+        L_a -= LA.col_mean(A).cpu().numpy()[:, None].astype(L_a.dtype)
+    if isinstance(L_b, np.ndarray) and np.issubdtype(L_b.dtype, np.floating):
+        L_b -= LA.col_mean(B).cpu().numpy()[:, None].astype(L_b.dtype)
+    return _cca_device(A, B)

@@ -1,0 +1,187 @@
+"""Multiview CCA alignment on the MI355X — drop-in surface of the reference's
+``alignment/AlignMCCA.py`` (AlignMCCA :13-138, get_MCCA_transforms :140, n_components_var :156).
+
+The reference delegates the arithmetic to ``mvlearn.embed.MCCA`` (:9, :152-153), which is not
+vendored, pinned or installed here: PARITY WITH MVLEARN IS UNPINNED.  This module
+implements the published regularised SUMCOR-MCCA generalised eigenproblem on the device:
+
+  G   = Zc^T Zc                 centred Gram of the concatenated views    xps_xcov_f64 (f64 MFMA)
+  R_b = (1 - r) G_bb + r I      per-view regularised covariance
+  LHS = G with diagonal blocks R_b ;  RHS = blockdiag(R_b)
+  R_b = V L V^T  ->  S = blockdiag(V L^-1/2 V^T)                          xps_jacobi_* per view
+  C   = S LHS S ,  top-k eigenpairs of C (Gershgorin shift + Jacobi)      xps_jacobi_*
+  loadings = rows of S V_k per view; sign rule on the normalised common scores
+  transform_view(X, i) = (X - mean_i) @ loadings_i                        xps_apply_f64
+"""
+import numpy as np
+
+from . import _linalg as LA
+from .alignment_utils import _group_conditions_device
+
+
+class DeviceMCCA:
+    """The object kept in ``AlignMCCA.mcca``: exposes what the reference uses of mvlearn's MCCA —
+    ``loadings_`` (list of (d_b, k) float64 arrays), ``transform_view(X2d, i)`` — plus ``means_``
+    and ``evals_``."""
+
+    def __init__(self, n_components=10, regs=0.5, signal_ranks=None):
+        self.n_components, self.regs, self.signal_ranks = n_components, regs, signal_ranks
+
+    def fit(self, views):
+        """views: list of (n, d_b) arrays / device tensors (one row per condition-time sample)."""
+        Vd = [LA.to_device(v).reshape(-1, v.shape[-1]) for v in views]
+        dims = [v.shape[1] for v in Vd]
+        offs = np.concatenate([[0], np.cumsum(dims)])
+        Z = LA.torch.cat([v.to(LA.F64) for v in Vd], dim=1).contiguous()
+        mean = LA.col_mean(Z)
+        G = LA.xcov(Z, None, mean).cpu().numpy()              # (D, D) centred Gram, f64 MFMA
+        self.means_ = [mean[offs[i]:offs[i + 1]].cpu().numpy() for i in range(len(Vd))]
+        self._means_d = [mean[offs[i]:offs[i + 1]].contiguous() for i in range(len(Vd))]
+        bases = None
+        if self.signal_ranks is not None:
+            # per-view rank-k PCA basis = top eigenvectors of G_bb; the problem is solved on the scores
+            bases = []
+            for i, r in enumerate(self.signal_ranks):
+                _, Vb = LA.eigh_psd(LA.to_device(G[offs[i]:offs[i + 1], offs[i]:offs[i + 1]]))
+                bases.append(Vb[:, :max(int(r), 1)])
+            Bm = _block_diag(bases)
+            G = LA.dgemm(LA.dgemm(LA.to_device(Bm), LA.to_device(G), ta=True), LA.to_device(Bm)).cpu().numpy()
+            dims = [b.shape[1] for b in bases]
+            offs = np.concatenate([[0], np.cumsum(dims)])
+        load_red, self.evals_ = _gevp(G, offs, self.n_components, self.regs)
+        if bases is not None:
+            load_red = [LA.dgemm(LA.to_device(b), LA.to_device(l)).cpu().numpy() for b, l in zip(bases, load_red)]
+        # sign rule: entry of largest magnitude of each normalised common-score column is positive
+        Vfull = LA.to_device(np.vstack(load_red))
+        common = LA.apply(Z, Vfull, mean).cpu().numpy()
+        common = common / np.linalg.norm(common, axis=0)
+        rows = np.argmax(np.abs(common), axis=0)
+        signs = np.sign(common[rows, np.arange(common.shape[1])])
+        signs[signs == 0] = 1
+        self.loadings_ = [l * signs for l in load_red]
+        self._load_d = [LA.to_device(np.ascontiguousarray(l)) for l in self.loadings_]
+        self.n_views_ = len(Vd)
+        return self
+
+    def transform_view(self, X, view):
+        return LA.apply(LA.to_device(X), self._load_d[view], self._means_d[view]).cpu().numpy()
+
+    def transform(self, Xs):
+        return [self.transform_view(x, i) for i, x in enumerate(Xs)]
+
+
+def _block_diag(blocks):
+    R, C = sum(b.shape[0] for b in blocks), sum(b.shape[1] for b in blocks)
+    out = np.zeros((R, C))
+    r = c = 0
+    for b in blocks:
+        out[r:r + b.shape[0], c:c + b.shape[1]] = b
+        r += b.shape[0]
+        c += b.shape[1]
+    return out
+
+
+def _gevp(G, offs, n_components, regs):
+    """Top generalised eigenpairs of (LHS, RHS) built from the Gram matrix G (host ndarray, D x D);
+    the decompositions run on the device.  Returns per-view loadings and the eigenvalues."""
+    P = len(offs) - 1
+    D = G.shape[0]
+    LHS = G.copy()
+    S = np.zeros_like(G)
+    for b in range(P):
+        sl = slice(offs[b], offs[b + 1])
+        Rb = G[sl, sl] if regs is None else (1.0 - regs) * G[sl, sl] + regs * np.eye(offs[b + 1] - offs[b])
+        LHS[sl, sl] = Rb
+        w, V = LA.eigh_psd(LA.to_device(Rb))
+        keep = w > w[0] * max(Rb.shape[0], 1) * LA.EPS          # guards a singular unregularised block
+        Vk = V[:, keep] / np.sqrt(w[keep])
+        S[sl, sl] = LA.dgemm(LA.to_device(Vk), LA.to_device(V[:, keep]), tb=True).cpu().numpy()   # R_b^-1/2
+    Sd = LA.to_device(S)
+    Cm = LA.dgemm(LA.dgemm(Sd, LA.to_device(LHS)), Sd)
+    Cm = 0.5 * (Cm + Cm.t())
+    k = min(n_components, D)
+    w, Vc = LA.eigh_sym_top(Cm, k)
+    Vg = LA.dgemm(Sd, LA.to_device(np.ascontiguousarray(Vc))).cpu().numpy()      # RHS-orthonormal
+    return [Vg[offs[b]:offs[b + 1]] for b in range(P)], w
+
+
+class AlignMCCA:
+    """MCCA-based alignment of multiple neural datasets into a shared space.
+
+    Attributes:
+        n_components (int), regs (float), pca_var (float): as in the reference (:27).
+        mcca: fitted DeviceMCCA (set after fit) with ``loadings_`` and ``transform_view``.
+    """
+
+    def __init__(self, n_components=10, regs=0.5, pca_var=1):
+        self.n_components = n_components
+        self.regs = regs
+        self.pca_var = pca_var
+
+    def get_params(self, deep=True):
+        return {'n_components': self.n_components, 'regs': self.regs, 'pca_var': self.pca_var}
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            setattr(self, k, v)
+        return self
+
+    def fit(self, X, y):
+        self.mcca = get_MCCA_transforms(X, y, n_components=self.n_components, regs=self.regs,
+                                        pca_var=self.pca_var)
+
+    def transform(self, X, idx=-1):
+        if not self._check_fit():
+            raise RuntimeError('Must call fit() before transforming data.')
+        if idx == -1:
+            return self._transform_multiple(X)
+        if idx >= len(self.mcca.loadings_):
+            raise IndexError('Input idx is greater than the number of learned '
+                             'transforms. For transformation of data from a '
+                             'specific session, provide the input idx as the '
+                             'index of the session in the input list. If '
+                             'transforming multiple sessions, set idx=-1 '
+                             '(default).')
+        return self._transform_single(X, idx)
+
+    def fit_transform(self, X, y):
+        self.fit(X, y)
+        return self.transform(X)
+
+    def _transform_multiple(self, X):
+        return (*[self._transform_single(x, i) for i, x in enumerate(X)],)
+
+    def _transform_single(self, X, idx):
+        shape = tuple(X.shape)
+        out = self.mcca.transform_view(X.reshape(-1, shape[-1]), idx)
+        return out.reshape(shape[:-1] + (-1,))
+
+    def _check_fit(self):
+        try:
+            self.mcca
+        except AttributeError:
+            return False
+        return True
+
+
+def get_MCCA_transforms(features, labels, n_components=10, regs=0.5, pca_var=1):
+    """Condition averages of the shared conditions -> flattened views -> optional per-view signal
+    ranks from the PCA variance of the RAW data (:146-150) -> MCCA fit."""
+    avgs = _group_conditions_device(features, labels)
+    avgs = [a.reshape(-1, a.shape[-1]) for a in avgs]
+    ranks = None
+    if pca_var > 0 and pca_var < 1:
+        ranks = [min(n_components, n_components_var(x, pca_var)) for x in features]
+    return DeviceMCCA(n_components=n_components, regs=regs, signal_ranks=ranks).fit(avgs)
+
+
+def n_components_var(X, var):
+    """Index of the first component at which the cumulative variance of the UNCENTRED data exceeds
+    ``var`` (reference :156-174).  NB this is ``argmax`` of a boolean array — a 0-based index, one
+    less than the component count; kept bug-compatible.  Squared singular values = eigenvalues of
+    X^T X (device Gram + Jacobi)."""
+    Xd = LA.to_device(X)
+    Xd = Xd.reshape(-1, Xd.shape[-1])
+    w, _ = LA.eigh_psd(LA.xcov(Xd))
+    s = w / np.sum(w)
+    return int(np.argmax(np.cumsum(s) > var))

@@ -1,0 +1,206 @@
+"""Device linear algebra for the aligners, on top of the C ABI (include/xps.h).
+
+Everything heavy — per-condition means, centred Gram / cross-covariance accumulation on the
+f64 MFMA, Jacobi eigen/singular decompositions, batched transform apply — runs in libxps.so.
+Host numpy only sorts / normalises / sign-fixes the small (d x d) results and builds index
+lists; there is no CPU fallback for the kernels.
+"""
+import numpy as np
+import torch
+
+from .._lib import call, lib
+
+F64 = torch.float64
+EPS = float(np.finfo(np.float64).eps)
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('cross_patient_speech_decoding_amd.alignment needs the MI355X: the HIP path has no '
+                           'CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device())
+
+
+def to_device(x):
+    """numpy / torch (float32 or float64; anything else -> float64) -> contiguous device tensor."""
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        x = np.asarray(x)
+        if x.dtype not in (np.float32, np.float64):
+            x = x.astype(np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(x))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(F64)
+    return t.to(device()).contiguous()
+
+
+def _is32(t):
+    return int(t.dtype == torch.float32)
+
+
+# ------------------------------------------------------------------------------------ k1
+def condition_index(keys):
+    """Sorted unique string keys + CSR (order, start) of the trials of each condition, trials in
+    original order inside a condition (numpy boolean-mask order)."""
+    uniq, inv = np.unique(np.asarray(keys), return_inverse=True)
+    order = np.argsort(inv, kind='stable').astype(np.int32)
+    start = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=len(uniq)))]).astype(np.int32)
+    return uniq, order, start
+
+
+def cnd_avg_device(data_d, order, start):
+    """data_d (N, ...) float32/float64 device tensor -> (n_cond, ...) float64 device tensor."""
+    n_cond = len(start) - 1
+    row_len = int(np.prod(data_d.shape[1:])) if data_d.dim() > 1 else 1
+    out = torch.empty((n_cond,) + tuple(data_d.shape[1:]), dtype=F64, device=data_d.device)
+    o = torch.from_numpy(order).to(data_d.device)
+    s = torch.from_numpy(start).to(data_d.device)
+    fn = 'xps_cnd_avg_f32' if data_d.dtype == torch.float32 else 'xps_cnd_avg_f64'
+    call(fn, data_d.data_ptr(), o.data_ptr(), s.data_ptr(), out.data_ptr(), n_cond, row_len, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------ k2
+def col_mean(X):
+    """Column means (float64) of an (n, d) device matrix."""
+    n, d = X.shape
+    out = torch.empty(d, dtype=F64, device=X.device)
+    nb = lib().xps_colsum_f64_workspace(n, d)
+    ws = _ws(nb)
+    call('xps_colsum_f64', X.data_ptr(), _is32(X), X.stride(0), n, d, out.data_ptr(), ws.data_ptr(), nb, _stream())
+    return out / n
+
+
+def xcov(A, B=None, mean_a=None, mean_b=None):
+    """(A - mean_a)^T (B - mean_b) in float64 on the f64 MFMA.  A (n, da), B (n, db) device."""
+    B = A if B is None else B
+    if B is A and mean_b is None:
+        mean_b = mean_a
+    n, da = A.shape
+    db = B.shape[1]
+    C = torch.empty(da, db, dtype=F64, device=A.device)
+    nb = lib().xps_xcov_f64_workspace(n, da, db)
+    ws = _ws(nb)
+    call('xps_xcov_f64', A.data_ptr(), _is32(A), A.stride(0), None if mean_a is None else mean_a.data_ptr(),
+         B.data_ptr(), _is32(B), B.stride(0), None if mean_b is None else mean_b.data_ptr(),
+         C.data_ptr(), db, n, da, db, ws.data_ptr(), nb, _stream())
+    return C
+
+
+def dgemm(A, B, ta=False, tb=False):
+    """op(A) @ op(B) for small float64 device matrices."""
+    A, B = A.contiguous(), B.contiguous()
+    M = A.shape[1] if ta else A.shape[0]
+    K = A.shape[0] if ta else A.shape[1]
+    N = B.shape[0] if tb else B.shape[1]
+    C = torch.empty(M, N, dtype=F64, device=A.device)
+    call('xps_dgemm_small', A.data_ptr(), A.stride(0), int(ta), B.data_ptr(), B.stride(0), int(tb), C.data_ptr(), N,
+         M, N, K, _stream())
+    return C
+
+
+def apply(X, W, mean=None, out_f32=False):
+    """(X - mean) @ W over all rows of X (..., d_in) -> (..., d_out).  W float64 (d_in, d_out)."""
+    W = W.contiguous()
+    X2 = X.reshape(-1, X.shape[-1])
+    n, d_in = X2.shape
+    d_out = W.shape[1]
+    Y = torch.empty(n, d_out, dtype=torch.float32 if out_f32 else F64, device=X.device)
+    call('xps_apply_f64', X2.data_ptr(), _is32(X2), X2.stride(0), None if mean is None else mean.data_ptr(),
+         W.data_ptr(), W.stride(0), Y.data_ptr(), int(out_f32), d_out, n, d_in, d_out, _stream())
+    return Y.view(*X.shape[:-1], d_out)
+
+
+# ------------------------------------------------------------------------------------ k3 / k5
+def _jacobi(Wc, n_cols, m_rows, max_sweeps=40, tol=1e-14):
+    """Wc: (n_cols, m_rows) float64 device tensor = column-major (m x n) matrix.  Rotates in place;
+    returns V (n_cols x n_cols as rows = columns of V, i.e. V^T in row-major terms)."""
+    Vc = torch.eye(n_cols, dtype=F64, device=Wc.device)
+    off = torch.zeros(1, dtype=F64, device=Wc.device)
+    done = 0
+    while done < max_sweeps:
+        k = 6 if done == 0 else 2
+        call('xps_jacobi_sweeps_f64', Wc.data_ptr(), Wc.stride(0), Vc.data_ptr(), n_cols, m_rows, n_cols, k,
+             off.data_ptr(), None, 0, _stream())
+        done += k
+        if off.item() <= tol:
+            break
+    return Vc
+
+
+def svd(A):
+    """Thin SVD of a small float64 device matrix by one-sided Jacobi: A = U diag(s) Vt, s descending.
+    Returns numpy (U, s, Vt)."""
+    A = A.to(F64)
+    m, n = A.shape
+    if m < n:
+        U, s, Vt = svd(A.t().contiguous())
+        return Vt.T, s, U.T
+    Wc = A.t().contiguous().clone()                 # row j = column j of A
+    Vc = _jacobi(Wc, n, m)
+    W = Wc.cpu().numpy()                            # (n, m): row j = u_j * s_j
+    V = Vc.cpu().numpy()                            # (n, n): row j = v_j
+    s = np.linalg.norm(W, axis=1)
+    order = np.argsort(-s, kind='stable')
+    s, W, V = s[order], W[order], V[order]
+    U = np.zeros_like(W)
+    nz = s > 0
+    U[nz] = W[nz] / s[nz, None]
+    return U.T, s, V
+
+
+def eigh_psd(C):
+    """Eigendecomposition of a symmetric PSD float64 device matrix (Jacobi): returns numpy
+    (w descending, V with eigenvectors in columns)."""
+    C = C.to(F64)
+    n = C.shape[0]
+    Wc = C.contiguous().clone()
+    Vc = _jacobi(Wc, n, n)
+    W = Wc.cpu().numpy()
+    V = Vc.cpu().numpy()
+    w = np.linalg.norm(W, axis=1)
+    order = np.argsort(-w, kind='stable')
+    return w[order], V[order].T
+
+
+def eigh_sym_top(C, k):
+    """Top-k (algebraically largest) eigenpairs of a symmetric, possibly indefinite, float64 device
+    matrix: shift by a Gershgorin bound so the matrix is PSD, Jacobi, unshift."""
+    C = C.to(F64)
+    Ch = C.cpu().numpy()
+    mu = float(np.abs(Ch).sum(axis=1).max())
+    n = C.shape[0]
+    Cs = C + mu * torch.eye(n, dtype=F64, device=C.device)
+    w, V = eigh_psd(Cs)
+    return (w - mu)[:k], V[:, :k]
+
+
+def rank_from_gram_eigs(w, n_rows):
+    """Numerical rank of an (n_rows x d) matrix from the eigenvalues of its Gram matrix.
+
+    LAPACK's matrix_rank (used by the reference, AlignCCA.py:263-264) thresholds singular values
+    at s_max * max(shape) * eps.  A Gram-based method cannot resolve singular values below
+    sqrt(eps)-ish of s_max, so the threshold here is on the eigenvalues: w > w_max * max(shape) *
+    eps (i.e. s > s_max * sqrt(max(shape) * eps)).  The two rules agree unless the condition number
+    of the data lies between ~1e5 and ~1e10 (documented in DESIGN.md)."""
+    if len(w) == 0 or w[0] <= 0:
+        return 0
+    tol = w[0] * max(n_rows, len(w)) * EPS
+    return int((w > tol).sum())
+
+
+def pinv_small(M):
+    """numpy.linalg.pinv semantics (rcond = 1e-15 on singular values) through the Jacobi SVD."""
+    U, s, Vt = svd(to_device(M))
+    cutoff = 1e-15 * (s.max() if len(s) else 0.0)
+    inv = np.where(s > cutoff, 1.0 / np.where(s > cutoff, s, 1.0), 0.0)
+    return dgemm(to_device(Vt.T * inv), to_device(U), tb=True).cpu().numpy()

@@ -1,0 +1,286 @@
+"""GPU parity of the alignment path (cnd_avg, CCA, MCCA, joint PCA, PCA) through the C ABI:
+against the golden vectors produced by the reference's own alignment package, against the CPU
+oracle on seeded inputs, and — at BASELINE full size — through size-independent properties.
+Tolerances: canon_corrs <= 1e-8, transform outputs <= 1e-6 relative, condition
+means bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import align_oracle as ao  # noqa: E402
+from oracle import mcca_oracle as mo  # noqa: E402
+
+
+def A():
+    import cross_patient_speech_decoding_amd.alignment as a
+    return a
+
+
+def LA():
+    from cross_patient_speech_decoding_amd.alignment import _linalg
+    return _linalg
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _match_up_to_sign(M, ref, tol):
+    assert M.shape == ref.shape
+    for j in range(M.shape[1]):
+        e = min(np.abs(M[:, j] - ref[:, j]).max(), np.abs(M[:, j] + ref[:, j]).max())
+        assert e <= tol * max(1.0, np.abs(ref[:, j]).max()), (j, e)
+
+
+# ------------------------------------------------------------------ condition means
+def test_cnd_avg_bit_exact_vs_reference_golden(golden_dir):
+    g = _load(golden_dir, 'align_labels.npz')
+    a = A()
+    avg1 = a.cnd_avg(g['X1'], a.label2str(g['y1']))
+    avg3 = a.cnd_avg(g['X3'], a.label2str(g['y3']))
+    assert avg1.dtype == np.float64 and avg3.dtype == np.float64
+    np.testing.assert_array_equal(avg1, g['avg1'])           # float64 input
+    np.testing.assert_array_equal(avg3, g['avg3'])           # float32 input: f32 sum, f32 divide, f64 store
+    out = a.extract_group_conditions([g['gXa'], g['gXb'], g['gXc']], [g['gya'], g['gyb'], g['gyc']])
+    for i in range(3):
+        np.testing.assert_array_equal(out[i], g[f'g{i}'])
+
+
+def test_cnd_avg_ragged_and_large():
+    rng = np.random.default_rng(0)
+    a = A()
+    # ragged: one condition with a single trial, one with many; float32
+    y = np.array([5] * 1 + [7] * 300 + [10] * 13)
+    X = rng.standard_normal((len(y), 9, 5)).astype(np.float32)
+    perm = rng.permutation(len(y))
+    X, y = X[perm], y[perm]
+    np.testing.assert_array_equal(a.cnd_avg(X, a.label2str(y)), ao.cnd_avg(X, ao.label_keys(y)))
+    # north-star sized slice: 2048 trials x 200 x 128 float32 (210 MB), 64 conditions
+    y = rng.integers(0, 64, 2048)
+    X = rng.standard_normal((2048, 200, 128), dtype=np.float32)
+    got = a.cnd_avg(X, a.label2str(y))
+    sel = [0, 17, 63]
+    keys = ao.label_keys(y)
+    uniq = np.unique(keys)
+    for c in sel:
+        np.testing.assert_array_equal(got[c], np.mean(X[keys == uniq[c]], axis=0).astype(np.float64))
+    # property: count-weighted mean of condition means == grand mean
+    counts = np.array([(keys == u).sum() for u in uniq])
+    np.testing.assert_allclose((got * counts[:, None, None]).sum(0) / len(y), X.mean(0, dtype=np.float64), atol=2e-5)
+
+
+# ------------------------------------------------------------------ CCA
+@pytest.mark.parametrize('case', ['full', 'uneq', 'rdef'])
+def test_align_cca_vs_reference_golden(golden_dir, case):
+    g = _load(golden_dir, 'align_cca.npz')
+    Xa, ya, Xb, yb = (g[f'{case}_{k}'] for k in ('Xa', 'ya', 'Xb', 'yb'))
+    al = A().AlignCCA(return_space='shared')
+    assert al.fit(Xa, Xb, ya, yb) is None
+    assert al.M_a.dtype == np.float64 and isinstance(al.canon_corrs, np.ndarray)
+    if case == 'rdef':
+        _check_rank_deficient(al, g, Xa, ya, Xb, yb)
+        return
+    np.testing.assert_allclose(al.canon_corrs, g[f'{case}_S'], rtol=0, atol=1e-8)
+    if case != 'rdef':
+        _match_up_to_sign(al.M_a, g[f'{case}_M_a'], 1e-7)
+        _match_up_to_sign(al.M_b, g[f'{case}_M_b'], 1e-7)
+        ta, tb = al.transform([Xa, Xb])
+        _match_up_to_sign(ta.reshape(-1, ta.shape[-1]), g[f'{case}_shared_ta'].reshape(-1, ta.shape[-1]), 1e-6)
+        _match_up_to_sign(tb.reshape(-1, tb.shape[-1]), g[f'{case}_shared_tb'].reshape(-1, tb.shape[-1]), 1e-6)
+    else:
+        assert al.M_b.shape == g['rdef_M_b'].shape == (7, 6)        # rank truncation reproduced
+    for space, X in (('b_to_a', Xb), ('a_to_b', Xa)):
+        al.return_space = space
+        al._maps = {}
+        out = al.transform(X)
+        ref = g[f'{case}_{space}_t']
+        assert out.shape == ref.shape and out.dtype == np.float64
+        rel = np.abs(out - ref).max() / np.abs(ref).max()
+        assert rel <= 1e-6, (space, rel)
+
+
+def _check_rank_deficient(al, g, Xa, ya, Xb, yb):
+    """View B has an exactly dependent channel (rank 6 of 7).  The reference's answer is then NOT
+    a function of the data alone: Householder QR of a rank-deficient matrix completes Q with a
+    direction built from rounding noise (AlignCCA.py:269-270), and that column enters the SVD
+    of Q_a^T Q_b (:273) with a chance correlation ~ 1/sqrt(n_samples).  The HIP path computes the
+    exact CCA on the rank-truncated space instead.  What must agree: the rank truncation
+    (shapes), and the values up to that chance-correlation term; what the HIP result must satisfy
+    exactly: the CCA optimality conditions."""
+    assert al.M_a.shape == g['rdef_M_a'].shape and al.M_b.shape == g['rdef_M_b'].shape == (7, 6)
+    assert np.abs(al.canon_corrs - g['rdef_S']).max() <= 0.05           # n = 170 samples -> ~0.08 chance level
+    La, Lb = ao.shared_class_dynamics(Xa, Xb, ya, yb)
+    La, Lb = La - La.mean(0), Lb - Lb.mean(0)
+    Pa, Pb = La @ al.M_a, Lb @ al.M_b
+    np.testing.assert_allclose(Pa.T @ Pa, np.eye(6), atol=1e-9)          # orthonormal canonical variates
+    np.testing.assert_allclose(Pb.T @ Pb, np.eye(6), atol=1e-9)
+    np.testing.assert_allclose(Pa.T @ Pb, np.diag(al.canon_corrs), atol=1e-9)   # diagonal = canonical corrs
+    # and they are the correlations scipy's exact subspace-angle computation gives on the true range spaces
+    import scipy.linalg
+    Lb_r = Lb[:, :6]                                                      # drop the dependent channel
+    ang = scipy.linalg.subspace_angles(La, Lb_r)
+    np.testing.assert_allclose(np.sort(np.cos(ang))[::-1][:6], al.canon_corrs, atol=1e-9)
+    al.return_space = 'b_to_a'
+    out = al.transform(Xb)
+    ref = g['rdef_b_to_a_t']
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() / np.abs(ref).max() <= 0.1
+
+
+def test_cca_align_function_and_inplace_centering(golden_dir):
+    g = _load(golden_dir, 'align_cca.npz')
+    La, Lb = g['raw_La'].copy(), g['raw_Lb'].copy()
+    Ma, Mb, S = A().CCA_align(La, Lb)
+    np.testing.assert_allclose(S, g['raw_S'], atol=1e-8)
+    _match_up_to_sign(Ma, g['raw_Ma'], 1e-7)
+    _match_up_to_sign(Mb, g['raw_Mb'], 1e-7)
+    np.testing.assert_allclose(La, g['raw_La'] - g['raw_La'].mean(1, keepdims=True), atol=1e-14)   # mutated like the reference
+
+
+def test_cca_errors_and_torch_input(golden_dir):
+    a = A()
+    with pytest.raises(RuntimeError, match=r'Must call fit\(\) before transforming data\.'):
+        a.AlignCCA().transform(np.zeros((2, 3, 4)))
+    with pytest.raises(ValueError, match='type must be "class" or "trial".'):
+        a.AlignCCA(type='bogus').fit(np.zeros((4, 3, 2)), np.zeros((4, 3, 2)), np.arange(4), np.arange(4))
+    g = _load(golden_dir, 'align_cca.npz')
+    al = a.AlignCCA()
+    al.fit(g['full_Xa'], g['full_Xb'], g['full_ya'], g['full_yb'])
+    out_t = al.transform(torch.from_numpy(g['full_Xb']))         # tensors arrive in realtime_datamodule.py:891
+    np.testing.assert_allclose(out_t, g['full_b_to_a_t'], rtol=0, atol=1e-6 * np.abs(g['full_b_to_a_t']).max())
+
+
+def test_cca_float32_large_seeded_vs_oracle():
+    """PCA-sized latent dims, float32 inputs, 64 conditions x 200 steps (n = 12800 samples)."""
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    Xa, ya = make_patient(0, 512, T=200, C=40)
+    Xb, yb = make_patient(1, 480, T=200, C=33)
+    ref = ao.AlignCCAOracle().fit(Xa, Xb, ya, yb)
+    al = A().AlignCCA()
+    al.fit(Xa, Xb, ya, yb)
+    np.testing.assert_allclose(al.canon_corrs, ref.canon_corrs, atol=1e-8)
+    out, exp = al.transform(Xb), ref.transform(Xb)
+    assert np.abs(out - exp).max() / np.abs(exp).max() <= 1e-6
+
+
+# ------------------------------------------------------------------ PCA / joint PCA
+def test_pca_vs_sklearn():
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((6000, 6)) @ rng.standard_normal((6, 24)) + 0.3 * rng.standard_normal((6000, 24)))
+    for dtype, tol in ((np.float64, 1e-9), (np.float32, 2e-5)):
+        Xd = X.astype(dtype)
+        p, Z = ao.pca_fit(Xd, 0.95)
+        q = A().PCA(n_components=0.95)
+        Zq = q.fit_transform(Xd)
+        assert q.n_components_ == p.n_components_
+        np.testing.assert_allclose(q.components_, p.components_, atol=tol * 10)
+        np.testing.assert_allclose(q.explained_variance_, p.explained_variance_, rtol=max(tol, 1e-9) * 10)
+        np.testing.assert_allclose(Zq, Z, atol=tol * 100)
+    q = A().PCA(n_components=5).fit(X)
+    assert q.components_.shape == (5, 24)
+
+
+def test_joint_pca_vs_reference_golden(golden_dir):
+    g = _load(golden_dir, 'align_jointpca.npz')
+    Xs, ys = [g[f'X{i}'] for i in range(3)], [g[f'y{i}'] for i in range(3)]
+    jp = A().JointPCA(n_components=4)
+    t = jp.fit_transform(Xs, ys)
+    assert isinstance(jp.transforms, tuple) and len(jp.transforms) == 3
+    for i in range(3):
+        np.testing.assert_allclose(jp.transforms[i], g[f'W{i}'], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(t[i], g[f't{i}'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(jp.transform(Xs[1], idx=1), g['t1_single'], rtol=1e-6, atol=1e-7)
+    with pytest.raises(IndexError, match='Input idx is greater than the number of learned'):
+        jp.transform(Xs[0], idx=3)
+    with pytest.raises(RuntimeError, match='Must call fit'):
+        A().JointPCA().transform(Xs)
+
+
+# ------------------------------------------------------------------ MCCA (parity unpinned vs mvlearn)
+def _mcca_data(seed=9):
+    rng = np.random.default_rng(seed)
+    seqs = np.array([[a, b, 2] for a in (1, 2, 3, 4) for b in (1, 2)])
+    Z = np.cumsum(rng.standard_normal((8, 12, 3)), axis=1)
+    feats, labs = [], []
+    for n, C in ((40, 6), (36, 8), (44, 5)):
+        c = np.concatenate([np.arange(8), rng.integers(0, 8, n - 8)])
+        feats.append(Z[c] @ rng.standard_normal((3, C)) + 0.2 * rng.standard_normal((n, 12, C)))
+        labs.append(seqs[c])
+    return feats, labs
+
+
+@pytest.mark.parametrize('pca_var', [1, 0.9])
+def test_align_mcca_vs_oracle_and_properties(pca_var):
+    feats, labs = _mcca_data()
+    ref = mo.get_mcca_transforms(feats, labs, n_components=3, regs=0.5, pca_var=pca_var)
+    al = A().AlignMCCA(n_components=3, regs=0.5, pca_var=pca_var)
+    out = al.fit_transform(feats, labs)
+    assert len(al.mcca.loadings_) == 3
+    np.testing.assert_allclose(al.mcca.evals_, ref.evals_, rtol=1e-9, atol=1e-10)
+    for i in range(3):
+        np.testing.assert_allclose(al.mcca.loadings_[i], ref.loadings_[i], rtol=1e-6, atol=1e-8)
+        exp = mo.mcca_transform(ref, feats[i], i)
+        assert out[i].shape == exp.shape
+        np.testing.assert_allclose(out[i], exp, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(al.transform(feats[i], idx=i), exp, rtol=1e-6, atol=1e-8)
+    if pca_var == 1:
+        # generalised-eigen residual and RHS-orthonormality of the device solution
+        views = [a.reshape(-1, a.shape[-1]) for a in ao.extract_group_conditions(feats, labs)]
+        views = [v - v.mean(0) for v in views]
+        LHS, RHS = mo.mcca_gevp_blocks(views, 0.5)
+        V = np.vstack(al.mcca.loadings_)
+        np.testing.assert_allclose(LHS @ V, RHS @ V * al.mcca.evals_, atol=1e-8 * np.abs(LHS).max())
+        np.testing.assert_allclose(V.T @ RHS @ V, np.eye(3), atol=1e-9)
+    with pytest.raises(IndexError, match='Input idx is greater than the number of learned'):
+        al.transform(feats[0], idx=3)
+    with pytest.raises(RuntimeError, match='Must call fit'):
+        A().AlignMCCA().transform(feats)
+
+
+def test_n_components_var_bug_compatible():
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((500, 7, 6)) * np.array([5, 3, 2, 1, 0.5, 0.1])
+    from cross_patient_speech_decoding_amd.alignment.AlignMCCA import n_components_var
+    assert n_components_var(X, 0.8) == mo.n_components_var(X.reshape(-1, 6), 0.8)
+
+
+# ------------------------------------------------------------------ kernels at BASELINE size
+def test_xcov_and_jacobi_full_size_properties():
+    la = LA()
+    rng = np.random.default_rng(1)
+    n, d = 409600, 128                               # one north-star patient: 2048 x 200 rows x 128 ch
+    X = torch.from_numpy(rng.standard_normal((n, d), dtype=np.float32) @ np.diag(np.linspace(0.2, 3, d)).astype(np.float32))
+    Xd = X.cuda()
+    mean = la.col_mean(Xd)
+    np.testing.assert_allclose(mean.cpu().numpy(), X.double().mean(0).numpy(), atol=1e-12)
+    C = la.xcov(Xd, None, mean).cpu().numpy()
+    ref = np.cov(X.double().numpy().T) * (n - 1)
+    assert np.abs(C - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert np.abs(C - C.T).max() <= 1e-9 * np.abs(C).max()
+    # determinism (split-K slabs, no atomics)
+    assert np.array_equal(C, la.xcov(Xd, None, mean).cpu().numpy())
+    w, V = la.eigh_psd(torch.from_numpy(C).cuda())
+    wr = np.linalg.eigvalsh(ref)[::-1]
+    np.testing.assert_allclose(w, wr, rtol=1e-10)
+    np.testing.assert_allclose(V.T @ V, np.eye(d), atol=1e-12)
+    np.testing.assert_allclose(V.T @ C @ V, np.diag(w), atol=1e-9 * w[0])
+
+
+def test_jacobi_eigh_d1024_and_svd():
+    la = LA()
+    rng = np.random.default_rng(2)
+    D = 1024                                         # north-star MCCA: 8 views x 128 channels
+    Bm = rng.standard_normal((D, 300))
+    C = Bm @ Bm.T + 0.5 * np.eye(D)
+    w, V = la.eigh_psd(torch.from_numpy(C).cuda())
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(C)[::-1], rtol=1e-10)
+    assert np.abs(V.T @ C @ V - np.diag(w)).max() <= 1e-9 * w[0]
+    M = rng.standard_normal((37, 52))
+    U, s, Vt = la.svd(torch.from_numpy(M).cuda())
+    np.testing.assert_allclose(s, np.linalg.svd(M, compute_uv=False), rtol=1e-12)
+    np.testing.assert_allclose((U * s) @ Vt, M, atol=1e-12)
+    np.testing.assert_allclose(la.pinv_small(M), np.linalg.pinv(M), atol=1e-12)
