@@ -1,0 +1,114 @@
+"""Spawned by the data-parallel tests: world ranks (gloo rendezvous on 127.0.0.1) each run one
+sharded training step and the result is compared with the single-process full-batch step.
+
+--device cuda : the HIP model on the box's single GPU (all ranks share cuda:0; gloo moves the
+                CUDA tensors) -> checks the product path: SyncBN statistics + flat all-reduce.
+--device cpu  : the host-side logic only (sharding, loss weighting, metric reduction, LinearLR),
+                with the CPU oracle as compute stand-in -> runs in the no-GPU CI."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+ARGS = (10, 12, 16, 9, 2, 1, 5, 5, 0, 0.0, 0.0)
+
+
+def data():
+    rng = np.random.default_rng(3)
+    X = torch.from_numpy(rng.standard_normal((46, 40, 10)).astype(np.float32))      # 46 rows: unequal shards at world 4
+    y = torch.from_numpy(rng.integers(0, 9, (46, 3)))
+    return X, y
+
+
+def hip_step(rank, world, X, y, group):
+    from weights import weights_from_seed
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    m = Seq2SeqRNN(*ARGS, 'gru', 1e-3, 1e-5, activation=True)
+    m.load_state_dict(weights_from_seed(m.state_dict(), 5))
+    m = m.cuda().train()
+    m.temporal_conv.process_group = group
+    opt = FlatAdamW(m, lr=1e-3, weight_decay=1e-5, max_norm=0.5, group=group)
+    xs, ys = X[rank::world].cuda(), y[rank::world].cuda()
+    opt.zero_grad()
+    logits = m(xs, ys, coins=[True, False, True])
+    loss = m.criterion(logits.view(-1, 9), ys.view(-1)) * (xs.shape[0] * world / X.shape[0])
+    loss.backward()
+    gnorm = opt.step()
+    return opt.flat_g.clone().cpu(), opt.flat_p.clone().cpu(), float(gnorm), m.temporal_conv.bn.running_var.cpu()
+
+
+def worker(rank, world, device, q):
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    X, y = data()
+    if device == 'cuda':
+        torch.cuda.set_device(0)
+        res = hip_step(rank, world, X, y, dist.group.WORLD)
+        if rank == 0:
+            q.put(res)
+    else:
+        from cross_patient_speech_decoding_amd.nn_models.trainer import LinearLR, Trainer, _shard
+        # shards partition the batch; the weighted local means add up to the global mean
+        xs = _shard(X, rank, world)
+        t = torch.tensor([float(xs.shape[0])]); dist.all_reduce(t)
+        assert int(t.item()) == X.shape[0]
+        local = xs.mean() * (xs.shape[0] * world / X.shape[0])
+        dist.all_reduce(local); local /= world
+        assert abs(local.item() - X.mean().item()) < 1e-6
+        tr = Trainer.__new__(Trainer); tr.group = None
+        tr._device = lambda: torch.device('cpu')
+        m = tr._reduce_metrics({'acc': float(rank + 1) * xs.shape[0]}, xs.shape[0])
+        exp = sum((r + 1) * len(X[r::world]) for r in range(world)) / X.shape[0]
+        assert abs(m['acc'] - exp) < 1e-9
+
+        class O:
+            base_lr = lr = 1.0
+        s = LinearLR(O, 1.0, 0.01, 10)
+        for _ in range(12):
+            s.step()
+        assert abs(O.lr - 0.01) < 1e-12
+        if rank == 0:
+            q.put('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--world', type=int, default=2)
+    ap.add_argument('--device', default='cpu')
+    a = ap.parse_args()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, a.world, a.device, q)) for r in range(a.world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, p.exitcode
+    if a.device == 'cuda':
+        X, y = data()
+        g1, p1, n1, rv1 = hip_step(0, 1, X, y, None)
+        g2, p2, n2, rv2 = res
+        eg = (g1 - g2).abs().max().item() / max(g1.abs().max().item(), 1e-12)
+        assert eg < 2e-4, f'gradient mismatch {eg}'
+        assert abs(n1 - n2) < 2e-4 * n1, (n1, n2)
+        assert (rv1 - rv2).abs().max().item() < 1e-5
+        # conv bias excluded from the weight check: zero-gradient noise through Adam (see test_gpu_seq2seq)
+        assert (p1 - p2).abs().max().item() < 2.5e-3
+    print('DP_OK')
+
+
+if __name__ == '__main__':
+    main()

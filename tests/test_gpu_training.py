@@ -1,0 +1,128 @@
+"""GPU tests of the training loop around the kernels: the PCA->CCA->pool pipeline, the Trainer
+(Lightning-like surface), trajectory / PER parity with the CPU oracle, and data-parallel
+equivalence (2 ranks, gloo rendezvous, both on the single GPU of the box)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pooled_views(P=3, N=96, T=40, C=(14, 12, 10), n_cond=12):
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    out = []
+    for p in range(P):
+        X, y = make_patient(p, N - 8 * p, T=T, C=C[p], n_cond=n_cond)
+        out.append((X, y - 1))
+    return out
+
+
+def test_process_aligner_matches_oracle():
+    from oracle import align_oracle as ao
+    from cross_patient_speech_decoding_amd.alignment import AlignCCA
+    from cross_patient_speech_decoding_amd.nn_models.data_utils.datamodules import process_aligner
+    views = _pooled_views()
+    (Xt, yt), pool = views[0], [(x, y, y) for x, y in views[1:]]
+    ref_X, ref_y, ref_tar = ao.process_aligner(Xt, yt, yt, pool)
+    Xp, yp, tar = process_aligner(torch.from_numpy(Xt), torch.from_numpy(yt), torch.from_numpy(yt),
+                                  [(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(a)) for x, y, a in pool],
+                                  AlignCCA)
+    assert Xp.dtype == torch.float32 and yp.dtype == torch.int64
+    assert tuple(Xp.shape) == ref_X.shape and tar.n_components_ == ref_tar.n_components_
+    np.testing.assert_array_equal(yp.numpy(), ref_y)
+    assert np.abs(Xp.numpy() - ref_X).max() <= 2e-4 * np.abs(ref_X).max()      # float32 inputs, float32 output
+    z = tar.transform(Xt.reshape(-1, Xt.shape[-1])[:50])
+    np.testing.assert_allclose(z, ref_tar.transform(Xt.reshape(-1, Xt.shape[-1])[:50]), atol=2e-4)
+
+
+def test_process_aligner_multiview_mcca_runs_and_aligns():
+    from cross_patient_speech_decoding_amd.alignment import AlignMCCA
+    from cross_patient_speech_decoding_amd.nn_models.data_utils.datamodules import process_aligner_multiview
+    views = _pooled_views()
+    (Xt, yt), pool = views[0], [(x, y, y) for x, y in views[1:]]
+    Xp, yp, tmap = process_aligner_multiview(Xt, yt, yt, pool, lambda: AlignMCCA(n_components=4, regs=0.5))
+    assert Xp.shape == (sum(v[0].shape[0] for v in views), 40, 4) and yp.shape == (Xp.shape[0], 3)
+    z = tmap.transform(Xt.reshape(-1, Xt.shape[-1]))
+    np.testing.assert_allclose(z.reshape(Xt.shape[0], 40, 4), Xp[:Xt.shape[0]].numpy(), atol=1e-4)
+
+
+def test_trainer_fit_test_and_logged_metrics():
+    from torch.utils.data import DataLoader, TensorDataset
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    from cross_patient_speech_decoding_amd.nn_models.trainer import ModelCheckpoint, Trainer, seed_everything
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    seed_everything(0)
+    X, y = make_patient(0, 256, T=60, C=16, n_cond=8)
+    X, y = torch.from_numpy(X), torch.from_numpy(y - 1)
+    tr = DataLoader(TensorDataset(X[:192], y[:192]), batch_size=5000, shuffle=True)
+    va = DataLoader(TensorDataset(X[192:], y[192:]), batch_size=5000)
+    model = Seq2SeqRNN(16, 12, 24, 9, 2, 1, 6, 6, 0, 0.1, 0.1, 'gru', 5e-3, 1e-5, activation=False, decay_iters=40)
+    ck = ModelCheckpoint(monitor='val_acc', mode='max')
+    trainer = Trainer(max_epochs=40, gradient_clip_val=0.5, callbacks=[ck])
+    trainer.fit(model, tr, va)
+    m = trainer.logged_metrics
+    for k in ('train_loss', 'train_acc', 'val_loss', 'val_acc'):
+        assert k in m
+    assert m['train_loss'] < 1.9 and m['train_acc'] > 0.2           # chance: ln 9 = 2.197, 0.111
+    assert abs(m['lr'] - 5e-3 * (1 - 0.99 * 39 / 40)) < 1e-9        # LinearLR 1.0 -> 0.01, stepped per epoch
+    res = trainer.test(model, va, ckpt_path='best')
+    assert 'test_acc' in trainer.logged_metrics and res[0]['test_acc'] == pytest.approx(ck.best_score, abs=1e-6)
+
+
+def test_training_trajectory_and_per_match_cpu_oracle():
+    """40 full-batch steps from identical weights, dropout 0, identical teacher-forcing coins:
+    loss curve within 2e-3, final PER within 0.5 % absolute (north-star tolerance)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from weights import weights_from_seed
+    from oracle.seq2seq_oracle import Seq2SeqOracle, phoneme_error_rate, train_step
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    torch.set_num_threads(8)
+    X, y = make_patient(3, 320, T=80, C=20, n_cond=10)
+    X, y = torch.from_numpy(X), torch.from_numpy(y - 1)
+    args = (20, 16, 32, 9, 2, 1, 8, 8, 0, 0.0, 0.0)
+    orc = Seq2SeqOracle(*args, learning_rate=3e-3, l2_reg=1e-5, activation=False)
+    sd = weights_from_seed(orc.state_dict(), 77)
+    orc.load_state_dict(sd)
+    hip = Seq2SeqRNN(*args, 'gru', 3e-3, 1e-5, activation=False)
+    hip.load_state_dict(sd)
+    hip = hip.cuda()
+    opt_o, _ = orc.make_optimizer()
+    opt_h = FlatAdamW(hip, lr=3e-3, weight_decay=1e-5, max_norm=0.5)
+    rng = np.random.default_rng(5)
+    Xg, yg = X.cuda(), y.cuda()
+    worst = 0.0
+    for step in range(40):
+        coins = [bool(c) for c in rng.integers(0, 2, 3)]
+        lo, _ = train_step(orc, opt_o, X, y, coins=coins, clip=0.5)
+        hip.train()
+        opt_h.zero_grad()
+        logits = hip(Xg, yg, coins=coins)
+        lh = hip.criterion(logits.view(-1, 9), yg.view(-1))
+        lh.backward()
+        opt_h.step()
+        worst = max(worst, abs(lh.item() - lo.item()))
+    assert worst <= 2e-3, worst
+    orc.eval(); hip.eval()
+    with torch.no_grad():
+        po = orc(X, y, teacher_forcing_ratio=0).argmax(-1).numpy()
+        ph = hip(Xg, yg, teacher_forcing_ratio=0).argmax(-1).cpu().numpy()
+    per_o, per_h = phoneme_error_rate(po, y.numpy()), phoneme_error_rate(ph, y.numpy())
+    assert abs(per_o - per_h) <= 0.5, (per_o, per_h)
+    assert per_h < 80.0                                              # learned something (chance ~ 89 %)
+
+
+def test_data_parallel_two_ranks_equal_single_process():
+    """N-rank gradients (sharded batch, SyncBN statistics, flat all-reduce) == 1-rank gradients."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', '2', '--device', 'cuda'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert 'DP_OK' in out.stdout
