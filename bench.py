@@ -109,7 +109,7 @@ def time_dominant_kernel(model, c, iters=20):
     flops = 2 * Tp * B * 2 * 3 * H * H
     dur = res['gru_fwd_kernel']
     ach = flops / dur / 1e12
-    return {'bound': 'mfma', 'kernel': 'gru_fwd_kernel<true> (encoder layer, both directions, one launch)',
+    return {'bound': 'mfma', 'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions, one launch)',
             'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
             'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops}

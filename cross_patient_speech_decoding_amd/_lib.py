@@ -20,6 +20,13 @@ def rowmap(ld, rpg=1 << 30, gs=0):
     return RowMap(int(gs), int(ld), int(rpg), 0)
 
 
+class TnProblem(C.Structure):
+    """xps_tn_problem"""
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('colsum_a', C.c_void_p),
+                ('ra', RowMap), ('rb', RowMap), ('rc', RowMap),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('accumulate', C.c_int32)]
+
+
 class XpsError(RuntimeError):
     pass
 
@@ -35,6 +42,8 @@ SIGNATURES = {
     'xps_gemm_nn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp]),
     'xps_gemm_tn_f32_workspace': (_sz, [_i, _i, _i]),
     'xps_gemm_tn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'xps_gemm_tn_grouped_f32_workspace': (_sz, [_vp, _i]),
+    'xps_gemm_tn_grouped_f32': (_i, [_vp, _i, _vp, _sz, _vp]),
     'xps_colsum_f32_workspace': (_sz, [_i, _i]),
     'xps_colsum_f32': (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     'xps_gru_seq_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -47,7 +56,8 @@ SIGNATURES = {
     'xps_bn_bwd_reduce_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i64, _i, _vp, _sz, _vp]),
     'xps_bn_bwd_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _d, _vp, _i64, _i, _vp]),
     'xps_gather_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    'xps_scatter_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'xps_scatter_rows_f32_workspace': (_sz, [_i, _i, _i]),
+    'xps_scatter_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'xps_next_token': (_i, [_vp, _i, _vp, _i64, _vp, _vp, _i, _vp]),
     'xps_mask_scale_f32': (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),

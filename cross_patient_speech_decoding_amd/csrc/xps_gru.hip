@@ -162,7 +162,7 @@ struct GruBwdParams {
     const float* saved;
     const float* w_hh_t[2];
     float* dgi;
-    float* dgh;
+    float* dghn;
     float* dh0;
     int T, B, H, ndir, Hp, ldg, ldc;
 };
@@ -209,9 +209,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
                 p.dgi[o + j] = dar;
                 p.dgi[o + H + j] = daz;
                 p.dgi[o + 2 * H + j] = dan;
-                p.dgh[o + j] = dar;
-                p.dgh[o + H + j] = daz;
-                p.dgh[o + 2 * H + j] = danr;
+                p.dghn[(((long long)dir * T + t) * B + b) * H + j] = danr;
             }
             G[r * ldg + j] = dar;
             G[r * ldg + Hp + j] = daz;
@@ -260,6 +258,360 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident specialisation (H = 64 or 128).  W_hh (3H x H fp32; 196 KB at H = 128) is
+// loaded ONCE into the VGPRs of the workgroup's four waves (wave w owns hidden tiles w and w+4:
+// 2 tiles x 3 gates x 8 k-chunks x float4 = 192 VGPRs; one wave per SIMD, 512-register budget)
+// and reused for every time step: per step a wave issues 192 back-to-back MFMAs fed by 8
+// ds_read_b128 of the LDS hidden tile — no global or L2 traffic for weights inside the loop.
+//
+// Operand roles are SWAPPED relative to the streaming kernel: A = W_hh fragment (row = hidden
+// unit), B = h^T (col = trial), so D[row = unit 4*kq + i][col = trial n]: every lane owns FOUR
+// CONSECUTIVE hidden units of ONE trial, and all per-step traffic (gi in, h out, saved gates,
+// LDS state) is 16-byte vectors.  Activations use v_exp_f32 / v_rcp_f32 (abs error ~1e-7,
+// far inside the 1e-4 logit budget).
+// ---------------------------------------------------------------------------------------------
+__device__ inline float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ inline float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
+__device__ inline float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+#ifdef XPS_STAMP
+// Diagnostic build only (never shipped): per-wave cycle shares of the step loop, written to a
+// buffer of their own that no kernel reads.
+__device__ unsigned long long g_stamp[4096 * 8];
+#define STAMP(var)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(var)
+#endif
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p) {
+    constexpr int NT = H / 16, TPW = NT / 4, NC = H / 16, LDH = H + 4;
+    constexpr int NST = TPW * 5;               // 16-byte stores per lane and step: h, r, z, n, q per tile
+    __shared__ __attribute__((aligned(16))) float hs[2][GBM][LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y, b0 = blockIdx.x * GBM;
+    const int T = p.T, B = p.B;
+    const int ldy = p.ndir * H;
+    const float* __restrict__ W = p.w_hh[dir];
+    const float* __restrict__ bh = p.b_hh[dir];
+    const float* __restrict__ gi = p.gi + (long long)dir * T * B * 3 * H;
+    const int b = b0 + n;                      // this lane's trial
+    const bool live = b < B;
+    const int bc = live ? b : B - 1;
+    const bool do_save = p.saved != nullptr;
+#ifdef XPS_STAMP
+    unsigned long long st_entry = 0, st_loop = 0, st_exit = 0;
+    STAMP(st_entry)
+#endif
+
+    float w[TPW][3][NC][4];                    // A operand: W[g*H + j0 + n][16c + 4kq + e]
+    float4 bias[TPW][3];                       // b_hh of the lane's 4 output units
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int j0 = (wave + 4 * tt) * 16;
+            bias[tt][g] = *reinterpret_cast<const float4*>(bh + g * H + j0 + 4 * kq);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(W + (long long)(g * H + j0 + n) * H + 16 * c + 4 * kq);
+                w[tt][g][c][0] = v.x; w[tt][g][c][1] = v.y; w[tt][g][c][2] = v.z; w[tt][g][c][3] = v.w;
+            }
+        }
+
+    for (int i = tid; i < 2 * GBM * LDH; i += 256) (&hs[0][0][0])[i] = 0.f;
+    __syncthreads();
+    {
+        const int slot_h0 = (dir == 0) ? 0 : T + 1, slot_other = (dir == 0) ? T + 1 : 0;
+        for (int i = tid; i < GBM * H; i += 256) {
+            const int r = i / H, k = i % H, bb = b0 + r;
+            if (bb < B) {
+                const float v = p.h0 ? p.h0[((long long)dir * B + bb) * H + k] : 0.f;
+                hs[0][r][k] = v;
+                p.y_ext[((long long)slot_h0 * B + bb) * ldy + dir * H + k] = v;
+                p.y_ext[((long long)slot_other * B + bb) * ldy + dir * H + k] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // Results of step s are NOT stored at the end of step s: a CU retires stores at ~16 B/clk, so 40 KB
+    // per step would stall every wave ~2400 cycles at issue.  They are kept in registers (pend) and
+    // issued one per k-chunk inside the MFMA loop of step s+1, where the VMEM pipe is otherwise idle.
+    float4 pend[NST];
+    float* pend_y = nullptr;
+    float* pend_sv = nullptr;
+    auto issue_store = [&](int k) {            // k is a compile-time constant at every call site
+        const int tt = k % TPW, what = k / TPW;
+        const int j = (wave + 4 * tt) * 16 + 4 * kq;
+        if (what == 0) *reinterpret_cast<float4*>(pend_y + j) = pend[k];
+        else if (do_save) *reinterpret_cast<float4*>(pend_sv + (what - 1) * H + j) = pend[k];
+    };
+
+    // gi of step s+1 is requested before step s's epilogue so its latency hides under the gate math
+    float4 g_nxt[TPW][3];
+    {
+        const int t0 = (dir == 0) ? 0 : T - 1;
+        const float* gp = gi + ((long long)t0 * B + bc) * 3 * H;
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                g_nxt[tt][g] = *reinterpret_cast<const float4*>(gp + g * H + (wave + 4 * tt) * 16 + 4 * kq);
+    }
+#ifdef XPS_STAMP
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, acc_mfma = 0, acc_epi = 0, acc_store = 0, acc_bar = 0;
+    STAMP(st_loop)
+#endif
+    for (int s = 0; s < T; ++s) {
+        const int t = (dir == 0) ? s : T - 1 - s;
+        const int cur = s & 1;
+        STAMP(st0)
+        float4 g_in[TPW][3];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) g_in[tt][g] = g_nxt[tt][g];
+
+        f32x4 acc[TPW][3];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool flush = (s > 0) && live;
+        float4 hb[2];
+        hb[0] = *reinterpret_cast<const float4*>(&hs[cur][n][4 * kq]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) hb[(c + 1) & 1] = *reinterpret_cast<const float4*>(&hs[cur][n][16 * (c + 1) + 4 * kq]);
+            const float4 a4 = hb[c & 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tt][g][c][e], f4get(a4, e), acc[tt][g], 0, 0, 0);
+            if (flush) {
+#pragma unroll
+                for (int k = c; k < NST; k += NC) issue_store(k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP(st1)
+        if (s + 1 < T) {
+            const int tn = (dir == 0) ? s + 1 : T - 2 - s;
+            const float* gp = gi + ((long long)tn * B + bc) * 3 * H;
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    g_nxt[tt][g] = *reinterpret_cast<const float4*>(gp + g * H + (wave + 4 * tt) * 16 + 4 * kq);
+        }
+        // gates: lane owns units j0 + 4*kq + {0..3} of trial b
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int j = (wave + 4 * tt) * 16 + 4 * kq;
+            const float4 hp = *reinterpret_cast<const float4*>(&hs[cur][n][j]);
+            float o[4], r_[4], z_[4], n_[4], q_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rg = fast_sigmoid(f4get(g_in[tt][0], i) + acc[tt][0][i] + f4get(bias[tt][0], i));
+                const float zg = fast_sigmoid(f4get(g_in[tt][1], i) + acc[tt][1][i] + f4get(bias[tt][1], i));
+                const float q = acc[tt][2][i] + f4get(bias[tt][2], i);
+                const float ng = fast_tanh(f4get(g_in[tt][2], i) + rg * q);
+                o[i] = live ? ng + zg * (f4get(hp, i) - ng) : 0.f;
+                r_[i] = rg; z_[i] = zg; n_[i] = ng; q_[i] = q;
+            }
+            pend[0 * TPW + tt] = make_float4(o[0], o[1], o[2], o[3]);
+            pend[1 * TPW + tt] = make_float4(r_[0], r_[1], r_[2], r_[3]);
+            pend[2 * TPW + tt] = make_float4(z_[0], z_[1], z_[2], z_[3]);
+            pend[3 * TPW + tt] = make_float4(n_[0], n_[1], n_[2], n_[3]);
+            pend[4 * TPW + tt] = make_float4(q_[0], q_[1], q_[2], q_[3]);
+            *reinterpret_cast<float4*>(&hs[cur ^ 1][n][j]) = pend[tt];
+        }
+        pend_y = p.y_ext + ((long long)(t + 1) * B + bc) * ldy + dir * H;
+        pend_sv = do_save ? p.saved + (((long long)dir * T + t) * B + bc) * 4 * H : nullptr;
+        STAMP(st2)
+        STAMP(st3)
+        __syncthreads();
+#ifdef XPS_STAMP
+        {
+            unsigned long long st4;
+            STAMP(st4)
+            acc_mfma += st1 - st0; acc_epi += st2 - st1; acc_store += st3 - st2; acc_bar += st4 - st3;
+        }
+#endif
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) issue_store(k);
+    }
+#ifdef XPS_STAMP
+    STAMP(st_exit)
+    if (lane == 0) {
+        const int wid = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) & 4095;
+        g_stamp[wid * 8 + 0] = acc_mfma; g_stamp[wid * 8 + 1] = acc_epi;
+        g_stamp[wid * 8 + 2] = acc_store; g_stamp[wid * 8 + 3] = acc_bar;
+        g_stamp[wid * 8 + 4] = st_loop - st_entry; g_stamp[wid * 8 + 5] = st_exit - st_loop;
+        g_stamp[wid * 8 + 6] = st_entry; g_stamp[wid * 8 + 7] = st_exit;
+    }
+#endif
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p) {
+    constexpr int NT = H / 16, TPW = NT / 4, NC = 3 * H / 16, LDG = 3 * H + 4, LDC = H + 4;
+    constexpr int H4 = H / 4, GPT = GBM * H4 / 256;       // float4 groups of the 16 x H tile per thread
+    __shared__ __attribute__((aligned(16))) float G[GBM][LDG];
+    __shared__ __attribute__((aligned(16))) float Cy[GBM][LDC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int dir = blockIdx.y, b0 = blockIdx.x * GBM;
+    const int T = p.T, B = p.B;
+    const int ldy = p.ndir * H;
+    const float* __restrict__ WT = p.w_hh_t[dir];   // (H x 3H)
+
+    float w[TPW][NC][4];                             // A operand: WT[j0 + n][16c + 4kq + e]
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int j = (wave + 4 * tt) * 16 + n;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(WT + (long long)j * 3 * H + 16 * c + 4 * kq);
+            w[tt][c][0] = v.x; w[tt][c][1] = v.y; w[tt][c][2] = v.z; w[tt][c][3] = v.w;
+        }
+    }
+    for (int i = tid; i < GBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
+    for (int i = tid; i < GBM * LDC; i += 256) (&Cy[0][0])[i] = 0.f;
+    __syncthreads();
+
+    // inputs of the gate-gradient phase for one step: saved r,z,n,q, h_prev and dy (7 x float4 per group)
+    struct StepIn { float4 dy, rg, zg, ng, q, hp; };
+    StepIn nxt[GPT];
+    auto load_step = [&](int s_, StepIn (&dst)[GPT]) {
+        const int t_ = (dir == 0) ? s_ : T - 1 - s_;
+        const int slot_prev_ = (dir == 0) ? t_ : t_ + 2;
+#pragma unroll
+        for (int e = 0; e < GPT; ++e) {
+            const int idx = tid + 256 * e;
+            const int r = idx / H4, j = (idx % H4) * 4;
+            int b = b0 + r;
+            b = b < B ? b : B - 1;
+            const float* sv = p.saved + (((long long)dir * T + t_) * B + b) * 4 * H;
+            dst[e].dy = *reinterpret_cast<const float4*>(p.dy + ((long long)t_ * B + b) * ldy + dir * H + j);
+            dst[e].rg = *reinterpret_cast<const float4*>(sv + j);
+            dst[e].zg = *reinterpret_cast<const float4*>(sv + H + j);
+            dst[e].ng = *reinterpret_cast<const float4*>(sv + 2 * H + j);
+            dst[e].q = *reinterpret_cast<const float4*>(sv + 3 * H + j);
+            dst[e].hp = *reinterpret_cast<const float4*>(p.y_ext + ((long long)slot_prev_ * B + b) * ldy + dir * H + j);
+        }
+    };
+    load_step(T - 1, nxt);
+
+    constexpr int NST = GPT * 4;               // 16-byte stores per thread and step: dar, daz, dan, dan*r per group
+    for (int s = T - 1; s >= 0; --s) {
+        const int t = (dir == 0) ? s : T - 1 - s;
+        StepIn in[GPT];
+#pragma unroll
+        for (int e = 0; e < GPT; ++e) in[e] = nxt[e];
+        if (s > 0) load_step(s - 1, nxt);
+        // (1) gate gradients, 4 consecutive hidden units per thread-group; results go to LDS now and to
+        //     HBM later, one store per few k-chunks of the MFMA phase (the VMEM pipe is idle there)
+        float4 pend[NST];
+        bool pend_live[GPT];
+#pragma unroll
+        for (int e = 0; e < GPT; ++e) {
+            const int idx = tid + 256 * e;
+            const int r = idx / H4, j = (idx % H4) * 4, b = b0 + r;
+            float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, danr = dar, keep = dar, dan4 = dar;
+            pend_live[e] = b < B;
+            if (b < B) {
+                const float4 dy4 = in[e].dy;
+                const float4 cy4 = *reinterpret_cast<const float4*>(&Cy[r][j]);
+                const float4 rg = in[e].rg, zg = in[e].zg, ng = in[e].ng, q = in[e].q, hp = in[e].hp;
+                float o_dar[4], o_daz[4], o_dan[4], o_danr[4], o_keep[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dh = f4get(dy4, i) + f4get(cy4, i);
+                    const float r_ = f4get(rg, i), z_ = f4get(zg, i), n_ = f4get(ng, i);
+                    const float dn = dh * (1.f - z_);
+                    const float dz = dh * (f4get(hp, i) - n_);
+                    const float dan = dn * (1.f - n_ * n_);
+                    o_daz[i] = dz * z_ * (1.f - z_);
+                    o_dar[i] = dan * f4get(q, i) * r_ * (1.f - r_);
+                    o_dan[i] = dan;
+                    o_danr[i] = dan * r_;
+                    o_keep[i] = dh * z_;
+                }
+                dar = make_float4(o_dar[0], o_dar[1], o_dar[2], o_dar[3]);
+                daz = make_float4(o_daz[0], o_daz[1], o_daz[2], o_daz[3]);
+                danr = make_float4(o_danr[0], o_danr[1], o_danr[2], o_danr[3]);
+                keep = make_float4(o_keep[0], o_keep[1], o_keep[2], o_keep[3]);
+                dan4 = make_float4(o_dan[0], o_dan[1], o_dan[2], o_dan[3]);
+            }
+            pend[e * 4 + 0] = dar; pend[e * 4 + 1] = daz; pend[e * 4 + 2] = dan4; pend[e * 4 + 3] = danr;
+            *reinterpret_cast<float4*>(&G[r][j]) = dar;
+            *reinterpret_cast<float4*>(&G[r][H + j]) = daz;
+            *reinterpret_cast<float4*>(&G[r][2 * H + j]) = danr;
+            *reinterpret_cast<float4*>(&Cy[r][j]) = keep;
+        }
+        auto issue_store = [&](int k) {        // k compile-time at every call site
+            const int e = k / 4, what = k % 4;
+            const int idx = tid + 256 * e;
+            const int r = idx / H4, j = (idx % H4) * 4, b = b0 + r;
+            if (pend_live[e]) {
+                if (what < 3) *reinterpret_cast<float4*>(p.dgi + (((long long)dir * T + t) * B + b) * 3 * H + what * H + j) = pend[k];
+                else *reinterpret_cast<float4*>(p.dghn + (((long long)dir * T + t) * B + b) * H + j) = pend[k];
+            }
+        };
+        __syncthreads();
+
+        // (2) dh_{t-1} = z*dh + dgh W_hh : D[row = unit 4kq+i][col = trial n]
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const float4 c4 = *reinterpret_cast<const float4*>(&Cy[n][(wave + 4 * tt) * 16 + 4 * kq]);
+            acc[tt] = (f32x4){c4.x, c4.y, c4.z, c4.w};
+        }
+        float4 gb[2];
+        gb[0] = *reinterpret_cast<const float4*>(&G[n][4 * kq]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) gb[(c + 1) & 1] = *reinterpret_cast<const float4*>(&G[n][16 * (c + 1) + 4 * kq]);
+            const float4 a4 = gb[c & 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tt][c][e], f4get(a4, e), acc[tt], 0, 0, 0);
+            if (c % 2 == 0 && c / 2 < NST) issue_store(c / 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = NC / 2 + (NC % 2); k < NST; ++k) issue_store(k);
+        const bool live = b0 + n < B;
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const float4 o = live ? make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Cy[n][(wave + 4 * tt) * 16 + 4 * kq]) = o;
+        }
+        __syncthreads();
+    }
+    if (p.dh0) {
+        for (int i = tid; i < GBM * H; i += 256) {
+            const int r = i / H, k = i % H, b = b0 + r;
+            if (b < B) p.dh0[((long long)dir * B + b) * H + k] = Cy[r][k];
+        }
+    }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -299,6 +651,12 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     const size_t lds_bytes = (size_t)2 * GBM * p.ldh * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident state tile");
     dim3 grid(cdiv(B, GBM), ndir);
+    if (vec && (H == 128 || H == 64)) {
+        if (H == 128) hipLaunchKernelGGL(gru_fwd_resident_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gru_fwd_resident_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        XPS_CHECK_LAUNCH();
+        return XPS_OK;
+    }
     if (vec) {
         if (lds_bytes > 64 * 1024)
             if (hipFuncSetAttribute((const void*)gru_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { xps_set_error("hipFuncSetAttribute failed"); return XPS_E_HIP; }
@@ -313,13 +671,13 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
 }
 
 extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const float* saved,
-                                   const float* const* w_hh_t, float* dgi, float* dgh, float* dh0,
+                                   const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                                    int T, int B, int H, int ndir, void* stream) {
-    XPS_CHECK_ARG(dy && y_ext && saved && w_hh_t && dgi && dgh, "null argument");
+    XPS_CHECK_ARG(dy && y_ext && saved && w_hh_t && dgi && dghn, "null argument");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
     GruBwdParams p;
-    p.dy = dy; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dgh = dgh; p.dh0 = dh0;
+    p.dy = dy; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;
     p.Hp = ((H + 15) / 16) * 16;
     p.ldg = 3 * p.Hp + 4;
@@ -333,6 +691,12 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const fl
     const size_t lds_bytes = (size_t)GBM * (p.ldg + p.ldc) * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident gradient tile");
     dim3 grid(cdiv(B, GBM), ndir);
+    if (vec && (H == 128 || H == 64)) {
+        if (H == 128) hipLaunchKernelGGL(gru_bwd_resident_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gru_bwd_resident_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        XPS_CHECK_LAUNCH();
+        return XPS_OK;
+    }
     if (vec) {
         if (lds_bytes > 64 * 1024)
             if (hipFuncSetAttribute((const void*)gru_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { xps_set_error("hipFuncSetAttribute failed"); return XPS_E_HIP; }
@@ -345,6 +709,12 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const fl
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
+
+#ifdef XPS_STAMP
+extern "C" int xps_debug_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream) {
     XPS_CHECK_ARG(src && dst && rows >= 0 && cols >= 0, "bad argument");

@@ -33,21 +33,33 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X
     }
 }
 
-__global__ void colsum_stage2(const float* __restrict__ part, const float* __restrict__ part_sq, int nparts, int cols,
-                              float* __restrict__ out, float* __restrict__ out_sq, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// stage 2: one block per 64 columns; four row-groups fold the partials in a fixed order, then combine
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, const float* __restrict__ part_sq,
+                                                     int nparts, int cols, float* __restrict__ out,
+                                                     float* __restrict__ out_sq, int accumulate) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     float a = 0.f, a2 = 0.f;
-    for (int i = 0; i < nparts; ++i) {
-        a += part[(long long)i * cols + c];
-        if (part_sq) a2 += part_sq[(long long)i * cols + c];
+    if (c < cols) {
+        for (int i = q; i < nparts; i += 4) {
+            a += part[(long long)i * cols + c];
+            if (part_sq) a2 += part_sq[(long long)i * cols + c];
+        }
     }
-    if (accumulate) {
-        a += out[c];
-        if (out_sq) a2 += out_sq[c];
+    s1[q][l] = a;
+    s2[q][l] = a2;
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        a = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+        a2 = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
+        if (accumulate) {
+            a += out[c];
+            if (out_sq) a2 += out_sq[c];
+        }
+        out[c] = a;
+        if (out_sq) out_sq[c] = a2;
     }
-    out[c] = a;
-    if (out_sq) out_sq[c] = a2;
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, double count, float* mean, float* rstd,
@@ -147,23 +159,37 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const long l
     }
 }
 
-// one block per (table row, 64-column strip): ordered sum over the batch
-__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dout, const long long* __restrict__ idx,
-                                                           float* __restrict__ dtable, int B, int cols, int accumulate) {
-    __shared__ float s[4][64];
-    const int row = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    float a = 0.f;
+// scatter-add of batch rows into a small table, deterministic, two stages:
+// stage 1: block (strip of 64 columns, chunk of 64 batch rows) accumulates into an LDS copy of the
+//          table (each thread owns one (row-group, column): no atomics) and writes its partial table;
+// stage 2: partial tables are summed in chunk order.
+constexpr int SC_CHUNK = 64, SC_MAXROWS = 16;
+__global__ __launch_bounds__(256) void scatter_rows_stage1(const float* __restrict__ dout, const long long* __restrict__ idx,
+                                                           float* __restrict__ part, int B, int cols, int n_rows) {
+    __shared__ float tab[4][SC_MAXROWS][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    for (int r = 0; r < n_rows; ++r) tab[q][r][l] = 0.f;
+    const int b0 = blockIdx.y * SC_CHUNK;
+    const int b1 = min(B, b0 + SC_CHUNK);
     if (c < cols)
-        for (int b = q; b < B; b += 4)
-            if (idx[b] == row) a += dout[(long long)b * cols + c];
-    s[q][threadIdx.x & 63] = a;
+        for (int b = b0 + q; b < b1; b += 4) {
+            long long r = idx[b];
+            r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+            tab[q][r][l] += dout[(long long)b * cols + c];
+        }
     __syncthreads();
-    if (q == 0 && c < cols) {
-        const int l = threadIdx.x;
-        float v = (s[0][l] + s[1][l]) + (s[2][l] + s[3][l]);
-        float* p = dtable + (long long)row * cols + c;
-        *p = accumulate ? *p + v : v;
-    }
+    if (c < cols)
+        for (int r = q; r < n_rows; r += 4)
+            part[((long long)blockIdx.y * n_rows + r) * cols + c] = (tab[0][r][l] + tab[1][r][l]) + (tab[2][r][l] + tab[3][r][l]);
+}
+__global__ void scatter_rows_stage2(const float* __restrict__ part, int nchunks, float* __restrict__ dtable,
+                                    long long total, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float a = 0.f;
+    for (int k = 0; k < nchunks; ++k) a += part[(long long)k * total + i];
+    dtable[i] = accumulate ? dtable[i] + a : a;
 }
 
 __global__ void next_token_kernel(const float* __restrict__ logits, int C, const long long* __restrict__ teacher,
@@ -310,7 +336,7 @@ extern "C" int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, f
                            X, (long long)ldx, rows, cols, part, part_sq);
         XPS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream,
                        part, part_sq, nparts, cols, out, out_sq, accumulate);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -371,7 +397,7 @@ extern "C" int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const 
     hipLaunchKernelGGL(bn_bwd_stage1, dim3(cdiv(F, 64), nparts), dim3(256), 0, (hipStream_t)stream,
                        dout, out, y, mean, rstd, drop_mask, drop_scale, relu, (long long)rows, F, part);
     XPS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(2 * F, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(2 * F, 64)), dim3(256), 0, (hipStream_t)stream,
                        part, (const float*)nullptr, nparts, 2 * F, sums, (float*)nullptr, 0);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -402,11 +428,29 @@ extern "C" int xps_gather_rows_f32(const float* table, const int64_t* idx, float
     return XPS_OK;
 }
 
+extern "C" size_t xps_scatter_rows_f32_workspace(int B, int cols, int n_rows) {
+    if (B <= 0 || cols <= 0 || n_rows <= 0) return 16;
+    return (size_t)cdiv(B, SC_CHUNK) * n_rows * cols * sizeof(float) + 16;
+}
+
 extern "C" int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float* dtable, int B, int cols, int n_rows,
-                                    int accumulate, void* stream) {
+                                    int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     XPS_CHECK_ARG(dout && idx && dtable && B >= 0 && cols >= 1 && n_rows >= 1, "bad argument");
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(cols, 64), n_rows), dim3(256), 0, (hipStream_t)stream,
-                       dout, (const long long*)idx, dtable, B, cols, accumulate);
+    XPS_CHECK_ARG(n_rows <= SC_MAXROWS, "table has too many rows for the scatter kernel (max 16)");
+    if (workspace_bytes < xps_scatter_rows_f32_workspace(B, cols, n_rows) || !workspace) {
+        xps_set_error("xps_scatter_rows_f32: workspace too small");
+        return XPS_E_WORKSPACE;
+    }
+    const int nchunks = B > 0 ? cdiv(B, SC_CHUNK) : 0;
+    float* part = (float*)workspace;
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(scatter_rows_stage1, dim3(cdiv(cols, 64), nchunks), dim3(256), 0, (hipStream_t)stream,
+                           dout, (const long long*)idx, part, B, cols, n_rows);
+        XPS_CHECK_LAUNCH();
+    }
+    const long long total = (long long)n_rows * cols;
+    hipLaunchKernelGGL(scatter_rows_stage2, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, nchunks, dtable, total, accumulate);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from .._lib import RowMap, call, lib, rowmap
+from .._lib import RowMap, TnProblem, call, lib, rowmap
 
 _f32 = torch.float32
 
@@ -74,6 +74,36 @@ def gemm_tn(A, B, out, M, N, K, ra=None, rb=None, rc=None, accumulate=False):
     return out
 
 
+def tn_problem(A, B, out, M, N, K, ra=None, rb=None, rc=None, colsum_out=None, accumulate=False):
+    """One weight-gradient problem  out (+)= A^T B  (A: K x M, B: K x N) [+ colsum_out (+)= column sums of A]."""
+    return TnProblem(_ptr(A), _ptr(B), _ptr(out), _ptr(colsum_out), ra or rowmap(M), rb or rowmap(N),
+                     rc or rowmap(N), M, N, K, int(accumulate))
+
+
+def gemm_tn_grouped(problems, device):
+    """All problems in ONE split-K launch + ONE reduce launch (deterministic)."""
+    for i in range(0, len(problems), 12):
+        chunk = problems[i:i + 12]
+        arr = (TnProblem * len(chunk))(*chunk)
+        nbytes = lib().xps_gemm_tn_grouped_f32_workspace(arr, len(chunk))
+        ws = _ws(nbytes, device)
+        call('xps_gemm_tn_grouped_f32', arr, len(chunk), _ptr(ws), nbytes, _stream())
+
+
+# When a parameter already owns a contiguous .grad buffer (FlatAdamW points every .grad into ONE flat
+# buffer), weight gradients are accumulated straight into it by the GEMM epilogue and autograd gets
+# None: no temporary, no extra add kernel per parameter.
+DIRECT_GRAD = True
+
+
+def _grad_target(param, shape, device):
+    g = getattr(param, 'grad', None) if DIRECT_GRAD else None
+    if g is not None and g.is_contiguous() and tuple(g.shape) == tuple(shape) and g.dtype == _f32 and g.is_cuda:
+        return g, True, None
+    t = torch.empty(shape, dtype=_f32, device=device)
+    return t, False, t
+
+
 def colsum(X, rows, cols, out=None, out_sq=None, ldx=None, accumulate=False):
     out = out if out is not None else torch.empty(cols, dtype=_f32, device=X.device)
     nbytes = lib().xps_colsum_f32_workspace(rows, cols)
@@ -99,33 +129,42 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         _need_gpu(x, w, b)
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        w = w.contiguous()
+        wc = w.contiguous()
         M, K = x2.shape
-        N = w.shape[0]
+        N = wc.shape[0]
         y = torch.empty(M, N, dtype=_f32, device=x.device)
-        gemm_nt(x2, w, y, M, N, K, bias=b)
-        ctx.save_for_backward(x2, w)
-        ctx.has_bias = b is not None
+        gemm_nt(x2, wc, y, M, N, K, bias=b)
+        ctx.save_for_backward(x2, wc)
+        ctx.params = (w, b)
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
+        x2, wc = ctx.saved_tensors
+        w, b = ctx.params
         M, K = x2.shape
-        N = w.shape[0]
+        N = wc.shape[0]
         dy2 = dy.reshape(M, N).contiguous()
-        dx = dw = db = None
+        dx = rw = rb = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=_f32, device=dy.device)
-            gemm_nn(dy2, w, dx, M, K, N)
+            gemm_nn(dy2, wc, dx, M, K, N)
             dx = dx.view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, K, dtype=_f32, device=dy.device)
-            gemm_tn(dy2, x2, dw, N, K, M)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2, M, N)
-        return dx, dw, db
+        need_w, need_b = ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            dw, acc_w, rw = _grad_target(w, (N, K), dy.device)
+            db = acc_b = None
+            if need_b:
+                db, acc_b, rb = _grad_target(b, (N,), dy.device)
+                if acc_b != acc_w:                      # one accumulate flag per problem: fall back to temporaries
+                    dw = torch.empty(N, K, dtype=_f32, device=dy.device)
+                    db = torch.empty(N, dtype=_f32, device=dy.device)
+                    acc_w, rw, rb = False, dw, db
+            gemm_tn_grouped([tn_problem(dy2, x2, dw, N, K, M, colsum_out=db, accumulate=acc_w)], dy.device)
+            if not need_w:
+                rw = None
+        return dx, rw, rb
 
 
 def linear(x, w, b=None):
@@ -145,32 +184,46 @@ def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save):
 
 
 def _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
+    """BPTT kernel.  Returns dgi (ndir,T,B,3H), dghn (ndir,T,B,H), dh0."""
     dev = y_ext.device
     dy = dy_ext[1:T + 1]
     if not dy.is_contiguous():
         dy = dy.contiguous()
     w_t = [transpose(w, 3 * H, H) for w in w_hh]
     dgi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
-    dgh = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
+    dghn = torch.empty(ndir, T, B, H, dtype=_f32, device=dev)
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
-    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(y_ext), _ptr(saved), _ptr_array(w_t), _ptr(dgi), _ptr(dgh),
+    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(y_ext), _ptr(saved), _ptr_array(w_t), _ptr(dgi), _ptr(dghn),
          _ptr(dh0), T, B, H, ndir, _stream())
-    # recurrent weight / bias gradients: dW_hh = dgh^T h_prev  (h_prev = slots of y_ext)
-    ldy = ndir * H
-    dw_hh, db_hh = [], []
-    for d in range(ndir):
-        dw = torch.empty(3 * H, H, dtype=_f32, device=dev)
-        first_slot = 0 if d == 0 else 2
-        hprev = y_ext.view(-1)[first_slot * B * ldy + d * H:]
-        gemm_tn(dgh[d], hprev, dw, 3 * H, H, T * B, ra=rowmap(3 * H), rb=rowmap(ldy))
-        dw_hh.append(dw)
-        db_hh.append(colsum(dgh[d], T * B, 3 * H))
     if need_dh0:
         # gradient that arrived directly on the h0 slots of y_ext
         dh0[0] += dy_ext[0, :, :H]
         if ndir == 2:
             dh0[1] += dy_ext[T + 1, :, H:]
-    return dgi, dw_hh, db_hh, dh0
+    return dgi, dghn, dh0
+
+
+def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H, ndir):
+    """dW_hh = dgh^T h_prev and db_hh = colsum(dgh) as grouped-TN problems.  h_prev(t) are slots of
+    y_ext (forward: slots 0..T-1, reverse: slots 2..T+1); the r,z rows of dgh are dgi's, the n rows dghn."""
+    dev = y_ext.device
+    ldy = ndir * H
+    probs, rets = [], []
+    for d in range(ndir):
+        dw, acc_w, rw = _grad_target(w_hh_params[d], (3 * H, H), dev)
+        db, acc_b, rb = _grad_target(b_hh_params[d], (3 * H,), dev)
+        if acc_w != acc_b:
+            dw, acc_w = torch.empty(3 * H, H, dtype=_f32, device=dev), False
+            db, acc_b = torch.empty(3 * H, dtype=_f32, device=dev), False
+            rw, rb = dw, db
+        first_slot = 0 if d == 0 else 2
+        hprev = y_ext.view(-1)[first_slot * B * ldy + d * H:]
+        probs.append(tn_problem(dgi[d], hprev, dw, 2 * H, H, T * B, ra=rowmap(3 * H), rb=rowmap(ldy), rc=rowmap(H),
+                                colsum_out=db, accumulate=acc_w))
+        probs.append(tn_problem(dghn[d], hprev, dw[2 * H:], H, H, T * B, ra=rowmap(H), rb=rowmap(ldy), rc=rowmap(H),
+                                colsum_out=db[2 * H:], accumulate=acc_w))
+        rets.append((rw, rb))
+    return probs, rets
 
 
 class GRURecurFn(torch.autograd.Function):
@@ -190,6 +243,7 @@ class GRURecurFn(torch.autograd.Function):
         y_ext, saved = _gru_forward(gi, w_hh, b_hh, h0c, T, B, H, ndir, save)
         if save:
             ctx.save_for_backward(y_ext, saved, *w_hh)
+        ctx.params = wb
         ctx.dims = (T, B, H, ndir)
         ctx.has_h0 = h0 is not None
         return y_ext
@@ -198,16 +252,17 @@ class GRURecurFn(torch.autograd.Function):
     def backward(ctx, dy_ext):
         y_ext, saved, *w_hh = ctx.saved_tensors
         T, B, H, ndir = ctx.dims
-        dgi, dw_hh, db_hh, dh0 = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir,
-                                               ctx.has_h0 and ctx.needs_input_grad[1])
-        return (dgi, dh0, None, *dw_hh, *db_hh)
+        dgi, dghn, dh0 = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir,
+                                       ctx.has_h0 and ctx.needs_input_grad[1])
+        probs, rets = _recurrent_grad_problems(dgi, dghn, y_ext, ctx.params[:ndir], ctx.params[ndir:], T, B, H, ndir)
+        gemm_tn_grouped(probs, y_ext.device)
+        return (dgi, dh0, None, *[r[0] for r in rets], *[r[1] for r in rets])
 
 
 class GRULayerFn(torch.autograd.Function):
     """One (bi)directional GRU layer over a time-major input x (T, B, In):
-    input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel +
-    the three weight-gradient GEMMs per direction.  weights: per direction
-    (w_ih, w_hh, b_ih, b_hh)."""
+    input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel + ONE grouped
+    launch for all six weight/bias gradients.  weights: per direction (w_ih, w_hh, b_ih, b_hh)."""
 
     @staticmethod
     def forward(ctx, x, ndir, *wb):
@@ -226,6 +281,7 @@ class GRULayerFn(torch.autograd.Function):
         y_ext, saved = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
         if save:
             ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
+        ctx.params = wb
         ctx.dims = (T, B, H, ndir, In)
         return y_ext
 
@@ -234,19 +290,30 @@ class GRULayerFn(torch.autograd.Function):
         T, B, H, ndir, In = ctx.dims
         x, y_ext, saved, *w = ctx.saved_tensors
         w_ih, w_hh = w[:ndir], w[ndir:]
-        dgi, dw_hh, db_hh, _ = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, False)
+        wb = ctx.params
+        dgi, dghn, _ = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, False)
         dev = x.device
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, In, dtype=_f32, device=dev)
             for d in range(ndir):
                 gemm_nn(dgi[d], w_ih[d], dx, T * B, In, 3 * H, accumulate=(d > 0))
+        probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_ext, [wb[4 * d + 1] for d in range(ndir)],
+                                                  [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir)
+        rets_ih = []
+        for d in range(ndir):
+            dw, acc_w, rw = _grad_target(wb[4 * d + 0], (3 * H, In), dev)
+            db, acc_b, rb = _grad_target(wb[4 * d + 2], (3 * H,), dev)
+            if acc_w != acc_b:
+                dw, acc_w = torch.empty(3 * H, In, dtype=_f32, device=dev), False
+                db = torch.empty(3 * H, dtype=_f32, device=dev)
+                rw, rb = dw, db
+            probs.append(tn_problem(dgi[d], x, dw, 3 * H, In, T * B, colsum_out=db, accumulate=acc_w))
+            rets_ih.append((rw, rb))
+        gemm_tn_grouped(probs, dev)
         grads = []
         for d in range(ndir):
-            dw_ih = torch.empty(3 * H, In, dtype=_f32, device=dev)
-            gemm_tn(dgi[d], x, dw_ih, 3 * H, In, T * B)
-            db_ih = colsum(dgi[d], T * B, 3 * H)
-            grads += [dw_ih, dw_hh[d], db_ih, db_hh[d]]
+            grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]
         return (dx, None, *grads)
 
 
@@ -324,12 +391,12 @@ class TemporalConvFn(torch.autograd.Function):
         dy = torch.empty_like(y)
         call('xps_bn_bwd_apply_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
              _ptr(drop_mask), drop_scale, int(relu), _ptr(sums), count, _ptr(dy), rows, F, _stream())
+        # dW2[f][kk*C + c] = sum_m dy[m][f] * window[m][kk*C + c], m = (b, t'); conv-bias gradient = the
+        # column sums of dy, produced by the same launch
         dconv_b = torch.empty(F, dtype=_f32, device=dev)
-        colsum(dy, rows, F, out=dconv_b)
-        # dW2[f][kk*C + c] = sum_m dy[m][f] * window[m][kk*C + c], m = (b, t')
         dw2 = torch.empty(F, k * Cin, dtype=_f32, device=dev)
-        gemm_tn(dy, x, dw2, F, k * Cin, rows, ra=rowmap(B * F, rpg=Tp, gs=F),
-                rb=rowmap(stride * Cin, rpg=Tp, gs=T * Cin))
+        gemm_tn_grouped([tn_problem(dy, x, dw2, F, k * Cin, rows, ra=rowmap(B * F, rpg=Tp, gs=F),
+                                    rb=rowmap(stride * Cin, rpg=Tp, gs=T * Cin), colsum_out=dconv_b)], dev)
         dconv_w = dw2.view(F, k, Cin).permute(0, 2, 1).contiguous()
         return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 10
 
@@ -358,7 +425,10 @@ class GatherRowsFn(torch.autograd.Function):
         n_rows, cols = ctx.shape
         dout = dout.contiguous()
         dt = torch.empty(n_rows, cols, dtype=_f32, device=dout.device)
-        call('xps_scatter_rows_f32', _ptr(dout), _ptr(idx), _ptr(dt), idx.shape[0], cols, n_rows, 0, _stream())
+        nbytes = lib().xps_scatter_rows_f32_workspace(idx.shape[0], cols, n_rows)
+        ws = _ws(nbytes, dout.device)
+        call('xps_scatter_rows_f32', _ptr(dout), _ptr(idx), _ptr(dt), idx.shape[0], cols, n_rows, 0, _ptr(ws), nbytes,
+             _stream())
         return dt, None
 
 

@@ -72,6 +72,19 @@ int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra, const float* B, const 
                     int M, int N, int K, int accumulate,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Grouped form: up to 12 weight-gradient problems  C_p (+)= A_p^T B_p  in ONE launch (+ one
+ * reduce launch).  colsum_a, when not NULL, receives  colsum_a[m] (+)= sum_k A_p[k][m]  (the bias
+ * gradient) folded from the staged A tiles inside the same launch — no separate reduction pass.
+ * `probs` is a HOST array; it is copied into the kernel arguments.                        */
+typedef struct xps_tn_problem {
+    const float* A; const float* B; float* C; float* colsum_a;
+    xps_rowmap ra, rb, rc;
+    int32_t M, N, K, accumulate;
+} xps_tn_problem;
+size_t xps_gemm_tn_grouped_f32_workspace(const xps_tn_problem* probs, int n);
+int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* out[c] (+)= sum_r X[r][c] (and optionally sum_r X[r][c]^2 into out_sq), two-stage,
  * deterministic.  Bias gradients and BatchNorm batch statistics.               */
 size_t xps_colsum_f32_workspace(int rows, int cols);
@@ -98,11 +111,12 @@ int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* 
 /* Backward through the recurrence (BPTT).
  *   dy     [T][B][ndir*H]   gradient w.r.t. the layer output (actual time)
  *   w_hh_t [ndir] pointers to W_hh^T (H x 3H), see xps_transpose_f32
- *   dgi    [ndir][T][B][3H] gradient w.r.t. gi   (= w.r.t. input pre-activations)
- *   dgh    [ndir][T][B][3H] gradient w.r.t. h_{t-1} W_hh^T + b_hh
+ *   dgi    [ndir][T][B][3H] gradient w.r.t. gi   (= w.r.t. input pre-activations r, z, n)
+ *   dghn   [ndir][T][B][H]  n-gate part of the gradient w.r.t. (h_{t-1} W_hh^T + b_hh); its r and z
+ *                           parts equal those of dgi, so they are not stored twice
  *   dh0    [ndir][B][H]     gradient w.r.t. h0 (or NULL)                       */
 int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const float* saved,
-                        const float* const* w_hh_t, float* dgi, float* dgh, float* dh0,
+                        const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                         int T, int B, int H, int ndir, void* stream);
 
 int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
@@ -143,9 +157,11 @@ int xps_bn_bwd_apply_f32(const float* dout, const float* out, const float* y, co
 /* out[b][:] = table[idx[b]][:]  (embedding / precomputed input projection rows) */
 int xps_gather_rows_f32(const float* table, const int64_t* idx, float* out,
                         int B, int cols, int n_rows, void* stream);
-/* dtable[r][:] (+)= sum_{b: idx[b]==r} dout[b][:]  (deterministic) */
+/* dtable[r][:] (+)= sum_{b: idx[b]==r} dout[b][:]  (deterministic two-stage; n_rows <= 16) */
+size_t xps_scatter_rows_f32_workspace(int B, int cols, int n_rows);
 int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float* dtable,
-                         int B, int cols, int n_rows, int accumulate, void* stream);
+                         int B, int cols, int n_rows, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* next[b] = use_teacher[0] ? teacher[b*teacher_stride] : argmax_c logits[b][c]
  * (first maximal index, as torch.argmax); use_teacher is a DEVICE flag so the
  * decode loop has no host synchronisation.                                     */
