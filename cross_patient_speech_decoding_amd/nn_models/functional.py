@@ -404,6 +404,86 @@ class TemporalConvFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- #
 # decoder glue, dropout, loss                                                   #
 # --------------------------------------------------------------------------- #
+def decoder_supported(H, C, L):
+    return bool(lib().xps_decoder_supported(int(H), int(C), int(L)))
+
+
+class DecoderFn(torch.autograd.Function):
+    """All decode steps of a one-layer GRU decoder in ONE launch (xps_decoder_fwd_f32) and one
+    backward launch + one grouped weight-gradient launch.  Returns logits (B, L, C)."""
+
+    @staticmethod
+    def forward(ctx, table, h0, w_hh, b_hh, w_fc, b_fc, teacher, flags, start_token, L):
+        _need_gpu(table, h0, w_hh, w_fc)
+        table, h0c = table.contiguous(), h0.contiguous()
+        w_hh_c, b_hh_c, w_fc_c, b_fc_c = w_hh.contiguous(), b_hh.contiguous(), w_fc.contiguous(), b_fc.contiguous()
+        B, H = h0c.shape
+        C = w_fc_c.shape[0]
+        ntok = table.shape[0]
+        dev = h0c.device
+        save = any(ctx.needs_input_grad)
+        logits = torch.empty(B, L, C, dtype=_f32, device=dev)
+        tokens = torch.empty(L, B, dtype=torch.int64, device=dev)
+        hs = torch.empty(L + 1, B, H, dtype=_f32, device=dev)
+        saved = torch.empty(L, B, 4 * H, dtype=_f32, device=dev) if save else None
+        if teacher is not None:
+            teacher = teacher.contiguous()
+            if tuple(teacher.shape) != (B, L):
+                raise ValueError('teacher tokens must be (batch, seq_length)')
+        call('xps_decoder_fwd_f32', _ptr(table), _ptr(w_hh_c), _ptr(b_hh_c), _ptr(h0c), _ptr(w_fc_c), _ptr(b_fc_c),
+             _ptr(teacher), _ptr(flags) if teacher is not None else None, _ptr(logits), _ptr(tokens), _ptr(hs),
+             _ptr(saved), B, H, C, L, ntok, int(start_token), _stream())
+        if save:
+            ctx.save_for_backward(tokens, hs, saved, w_hh_c, w_fc_c)
+        ctx.params = (w_hh, b_hh, w_fc, b_fc)
+        ctx.dims = (B, H, C, L, ntok)
+        ctx.mark_non_differentiable(tokens)
+        return logits, tokens
+
+    @staticmethod
+    def backward(ctx, dlogits, _dtok):
+        tokens, hs, saved, w_hh_c, w_fc_c = ctx.saved_tensors
+        B, H, C, L, ntok = ctx.dims
+        w_hh, b_hh, w_fc, b_fc = ctx.params
+        dev = hs.device
+        dlogits = dlogits.contiguous()
+        w_t = transpose(w_hh_c, 3 * H, H)
+        dgi = torch.empty(L, B, 3 * H, dtype=_f32, device=dev)
+        dghn = torch.empty(L, B, H, dtype=_f32, device=dev)
+        dh0 = torch.empty(B, H, dtype=_f32, device=dev)
+        call('xps_decoder_bwd_f32', _ptr(dlogits), _ptr(hs), _ptr(saved), _ptr(w_t), _ptr(w_fc_c), _ptr(dgi), _ptr(dghn),
+             _ptr(dh0), B, H, C, L, _stream())
+        # weight gradients: W_hh / b_hh from (dgi, dghn) x h_prev = hs[0:L];  W_fc / b_fc from dlogits x hs[1:L+1]
+        dwh, acc_h, r_wh = _grad_target(w_hh, (3 * H, H), dev)
+        dbh, acc_bh, r_bh = _grad_target(b_hh, (3 * H,), dev)
+        dwf, acc_f, r_wf = _grad_target(w_fc, (C, H), dev)
+        dbf, acc_bf, r_bf = _grad_target(b_fc, (C,), dev)
+        if not (acc_h == acc_bh and acc_f == acc_bf):
+            dwh, dbh = torch.empty(3 * H, H, dtype=_f32, device=dev), torch.empty(3 * H, dtype=_f32, device=dev)
+            dwf, dbf = torch.empty(C, H, dtype=_f32, device=dev), torch.empty(C, dtype=_f32, device=dev)
+            acc_h = acc_f = False
+            r_wh, r_bh, r_wf, r_bf = dwh, dbh, dwf, dbf
+        hprev = hs                                   # rows (s, b): hs[s]
+        hnext = hs.view(-1)[B * H:]                  # rows (s, b): hs[s + 1]
+        probs = [
+            tn_problem(dgi, hprev, dwh, 2 * H, H, L * B, ra=rowmap(3 * H), rb=rowmap(H), rc=rowmap(H),
+                       colsum_out=dbh, accumulate=acc_h),
+            tn_problem(dghn, hprev, dwh[2 * H:], H, H, L * B, ra=rowmap(H), rb=rowmap(H), rc=rowmap(H),
+                       colsum_out=dbh[2 * H:], accumulate=acc_h),
+            # dlogits is (B, L, C): row (s, b) lives at b*L*C + s*C
+            tn_problem(dlogits, hnext, dwf, C, H, L * B, ra=rowmap(L * C, rpg=B, gs=C), rb=rowmap(H), rc=rowmap(H),
+                       colsum_out=dbf, accumulate=acc_f),
+        ]
+        gemm_tn_grouped(probs, dev)
+        # d table[tok] += dgi over all (step, trial) rows
+        dtable = torch.empty(ntok, 3 * H, dtype=_f32, device=dev)
+        nbytes = lib().xps_scatter_rows_f32_workspace(L * B, 3 * H, ntok)
+        ws = _ws(nbytes, dev)
+        call('xps_scatter_rows_f32', _ptr(dgi), _ptr(tokens), _ptr(dtable), L * B, 3 * H, ntok, 0, _ptr(ws), nbytes,
+             _stream())
+        return dtable, dh0, r_wh, r_bh, r_wf, r_bf, None, None, None, None
+
+
 class GatherRowsFn(torch.autograd.Function):
     """out[b] = table[idx[b]] (nn.Embedding lookups / per-token input projections)."""
 

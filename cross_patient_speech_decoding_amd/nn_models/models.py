@@ -235,6 +235,16 @@ class Seq2SeqRNN(BaseLightningModel):
         decisions, so the whole step can be captured in a hipGraph."""
         z = self.temporal_conv.forward_tm(x)                       # (T', B, F)
         _, enc_hidden = self.encoder.forward_tm(z)                  # (1, B, H)
+        rnn = self.decoder.rnn
+        if (rnn.num_layers == 1 and self.num_classes + 1 <= 16
+                and XF.decoder_supported(rnn.hidden_size, self.num_classes, self.seq_length)):
+            # fused path: every decode step in one launch, tokens chosen on the device
+            table = self.decoder.token_projection()
+            logits, _ = XF.DecoderFn.apply(table, enc_hidden[0], rnn.weight_hh_l0, rnn.bias_hh_l0,
+                                           self.decoder.fc_out.weight, self.decoder.fc_out.bias,
+                                           y if y is not None else None, flags if y is not None else None,
+                                           self.num_classes, self.seq_length)
+            return logits
         dec_hidden = enc_hidden.repeat(self.decoder.rnn.num_layers, 1, 1)
         B = x.size(0)
         tok = torch.full((B,), self.num_classes, dtype=torch.long, device=x.device)

@@ -154,6 +154,25 @@ int xps_bn_bwd_apply_f32(const float* dout, const float* out, const float* y, co
 /* ------------------------------------------------------------------------- */
 /* Decoder glue (nn_models/models.py:285-299,758-761)                           */
 /* ------------------------------------------------------------------------- */
+/* Fused autoregressive decoder: all L decode steps of a ONE-layer GRU decoder in one launch
+ * (input-projection gather by token -> GRU cell, W_hh resident in registers -> Linear -> next token =
+ * teacher token if flags[s] else first-max argmax).  Supported: H in {64, 128}, C <= 16, L <= 8
+ * (xps_decoder_supported); other shapes use the composed entry points.
+ *   table  [ntok][3H]  E W_ih^T + b_ih        teacher [B][L] (or NULL)   flags [L] DEVICE int32 (or NULL)
+ *   logits [B][L][C]   tokens [L][B] input token of every step
+ *   hs     [L+1][B][H] hidden state before step s (slot s) / after it (slot s+1)
+ *   saved  [L][B][4H]  r, z, n, (W_hn h + b_hn)  (NULL in eval)
+ * backward: dlogits [B][L][C] -> dgi [L][B][3H], dghn [L][B][H], dh0 [B][H]; weight gradients follow
+ * from xps_gemm_tn_grouped_f32 / xps_scatter_rows_f32 over those buffers.                          */
+int xps_decoder_supported(int H, int C, int L);
+int xps_decoder_fwd_f32(const float* table, const float* w_hh, const float* b_hh, const float* h0,
+                        const float* w_fc, const float* b_fc, const int64_t* teacher, const int32_t* flags,
+                        float* logits, int64_t* tokens, float* hs, float* saved,
+                        int B, int H, int C, int L, int ntok, int start_token, void* stream);
+int xps_decoder_bwd_f32(const float* dlogits, const float* hs, const float* saved, const float* w_hh_t,
+                        const float* w_fc, float* dgi, float* dghn, float* dh0,
+                        int B, int H, int C, int L, void* stream);
+
 /* out[b][:] = table[idx[b]][:]  (embedding / precomputed input projection rows) */
 int xps_gather_rows_f32(const float* table, const int64_t* idx, float* out,
                         int B, int cols, int n_rows, void* stream);

@@ -121,3 +121,45 @@ def test_reference_coin_sequence_is_reproduced():
     a = torch.rand(1).item()
     torch.manual_seed(123)
     assert a == torch.rand(1).item()
+
+
+@pytest.mark.parametrize('H,B', [(64, 37), (128, 50)])
+def test_fused_decoder_equals_composed_path_and_oracle(H, B):
+    """The one-launch decoder (xps_decoder_*) against the composed per-step path of the same model and
+    against the CPU oracle: logits, argmax, and every parameter gradient, mixed teacher forcing."""
+    from oracle.seq2seq_oracle import Seq2SeqOracle
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    cfg = dict(in_channels=10, n_filters=12, hidden_size=H, n_enc_layers=1, n_dec_layers=1, kernel_size=5,
+               stride=5, activation=False)
+    rng = np.random.default_rng(H)
+    x = torch.from_numpy(rng.standard_normal((B, 30, 10)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 9, (B, 3)))
+    coins = [True, False, True]
+    orc = Seq2SeqOracle(10, 12, H, 9, 1, 1, 5, 5, 0, 0.0, 0.0, activation=False)
+    orc.load_state_dict(weights_from_seed(orc.state_dict(), 31))
+    orc.train()
+    ref = orc(x, y, coins=coins)
+    torch.nn.functional.cross_entropy(ref.reshape(-1, 9), y.reshape(-1)).backward()
+    results = {}
+    for fused in (True, False):
+        m = build_hip(cfg, 31).train()
+        orig = XF.decoder_supported
+        if not fused:
+            XF.decoder_supported = lambda *a: False
+        try:
+            out = m(x.cuda(), y.cuda(), coins=coins)
+            m.criterion(out.view(-1, 9), y.cuda().view(-1)).backward()
+        finally:
+            XF.decoder_supported = orig
+        results[fused] = (out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+    for fused in (True, False):
+        out, grads = results[fused]
+        assert (out - ref.detach()).abs().max().item() <= 1e-4
+        assert torch.equal(out.argmax(-1), ref.argmax(-1))
+        for k, p in orc.named_parameters():
+            if k == NOISE_KEY:
+                continue
+            tol = 2e-5 * max(1.0, p.grad.abs().max().item())
+            assert (grads[k] - p.grad).abs().max().item() <= tol + 2e-3 * p.grad.abs().max().item(), (fused, k)
+    # fused and composed agree with each other far below the oracle tolerance
+    assert (results[True][0] - results[False][0]).abs().max().item() <= 1e-5
