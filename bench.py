@@ -64,7 +64,10 @@ def cpu_baseline(c, budget_s=20.0):
     """The CPU oracle (plain torch.nn restatement of the reference, pinned to reference goldens) on
     the same workload, bounded: B = 256 trials per step, as many steps as fit the budget."""
     from oracle.seq2seq_oracle import Seq2SeqOracle, train_step
-    threads = torch.get_num_threads()
+    # the GPU box exposes far more logical CPUs than it may use (16-core share per GPU): oversubscribed
+    # small GEMMs run SLOWER, so the baseline uses at most 16 threads
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = Seq2SeqOracle(c['in_channels'], c['n_filters'], c['hidden_size'], c['num_classes'], c['n_enc_layers'],
                       c['n_dec_layers'], c['kernel_size'], c['stride'], 0, 0.3, 0.3, learning_rate=1e-4,
@@ -85,34 +88,65 @@ def cpu_baseline(c, budget_s=20.0):
                       f'fp32 torch.nn CPU oracle, {threads} threads, {el:.1f} s'}
 
 
-def time_dominant_kernel(model, c, iters=20):
-    """HIP-event timing (on the launch stream = torch's current stream) of the encoder's fused GRU
-    recurrence launch for the bench shape; algorithmic FLOPs = 2 dirs * T' * B * 2 * 3H * H."""
+def _event_time(fn, iters=20, warm=3):
+    """Average launch duration by HIP events on torch's current stream (= the stream the C ABI launches on)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def time_dominant_kernel(model, c):
+    """Roofline of the kernel with the largest share of the step (profiles/round1/r1b_*): the fp32-MFMA
+    GEMM tile kernel, measured on its largest single launch = the grouped weight-gradient GEMM of encoder
+    layer 1 (6 problems, K = T'*B rows).  Algorithmic FLOPs = sum 2*M*N*K over the group.  The fused GRU
+    recurrence (second largest) is reported beside it."""
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
     Tp = (c['T'] - c['kernel_size']) // c['stride'] + 1
     B, H = c['trials_per_gpu'], c['hidden_size']
+    K, In = Tp * B, 2 * H
+    dev = 'cuda'
+    dgi = torch.randn(2, K, 3 * H, device=dev) * 0.1
+    dghn = torch.randn(2, K, H, device=dev) * 0.1
+    x = torch.randn(K, In, device=dev)
+    y_ext = torch.randn(Tp + 2, B, 2 * H, device=dev)
+    outs = [(torch.empty(3 * H, In, device=dev), torch.empty(3 * H, device=dev), torch.empty(3 * H, H, device=dev),
+             torch.empty(3 * H, device=dev)) for _ in range(2)]
+
+    def launch():
+        probs = []
+        for d in range(2):
+            dw_ih, db_ih, dw_hh, db_hh = outs[d]
+            hprev = y_ext.view(-1)[(0 if d == 0 else 2) * B * 2 * H + d * H:]
+            probs.append(XF.tn_problem(dgi[d], hprev, dw_hh, 2 * H, H, K, ra=XF.rowmap(3 * H), rb=XF.rowmap(2 * H),
+                                       rc=XF.rowmap(H), colsum_out=db_hh))
+            probs.append(XF.tn_problem(dghn[d], hprev, dw_hh[2 * H:], H, H, K, ra=XF.rowmap(H), rb=XF.rowmap(2 * H),
+                                       rc=XF.rowmap(H), colsum_out=db_hh[2 * H:]))
+            probs.append(XF.tn_problem(dgi[d], x, dw_ih, 3 * H, In, K, colsum_out=db_ih))
+        XF.gemm_tn_grouped(probs, dev)
+    dur = _event_time(launch)
+    flops = 2 * (2 * K * (3 * H * H + 3 * H * In))
+    ach = flops / dur / 1e12
+    # second: the fused GRU recurrence of one encoder layer (both directions, one launch)
     rnn = model.encoder.rnn
     w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
     b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
-    gi = torch.randn(2, Tp, B, 3 * H, device='cuda') * 0.5
-    res = {}
-    for name, save in (('gru_fwd_kernel', True),):
-        for _ in range(3):
-            XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, save)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, save)
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3
-    flops = 2 * Tp * B * 2 * 3 * H * H
-    dur = res['gru_fwd_kernel']
-    ach = flops / dur / 1e12
-    return {'bound': 'mfma', 'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions, one launch)',
+    gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
+    dur_gru = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True))
+    fl_gru = 2 * Tp * B * 2 * 3 * H * H
+    return {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel (fp32 MFMA 128x128x16 tile; encoder layer-1 weight '
+                                       'gradients, 6 problems in one launch, incl. its reduce pass)',
             'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-            'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops}
+            'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops,
+            'also': {'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions)',
+                     'achieved': round(fl_gru / dur_gru / 1e12, 3), 'frac': round(fl_gru / dur_gru / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                     'launch_us': round(dur_gru * 1e6, 1), 'flops_per_launch': fl_gru}}
 
 
 def main():

@@ -5,7 +5,7 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libxps.so')
+LIB_PATH = os.environ.get('XPS_LIB_OVERRIDE') or os.path.join(_PKG, 'libxps.so')   # override: A/B builds in tools/
 HEADER_PATH = os.path.join(_PKG, '..', 'include', 'xps.h')
 
 _lib = None

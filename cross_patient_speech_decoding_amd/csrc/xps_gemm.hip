@@ -19,18 +19,28 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKT = 16, LDT = 132;
+#ifndef XPS_BKT
+#define XPS_BKT 16
+#endif
+#ifndef XPS_GEMM_WAVES
+#define XPS_GEMM_WAVES 1
+#endif
+constexpr int BM = 128, BN = 128, BKT = XPS_BKT, LDT = 132;
+
+constexpr int NV = BKT / 8;          // 16-byte vectors per thread, operand and k-tile
+constexpr int KL = BKT / 4;          // KCONTIG: lanes covering one row's k range
+constexpr int XR = 256 / KL;         // KCONTIG: rows of x covered per pass
 
 template <bool KCONTIG>
 struct TileLoader {
     // KCONTIG : matrix stored [x][k]  (x = m or n), 16-byte vectors along k
-    //           thread -> (x = tid>>2 (+64), k4 = (tid&3)*4)
+    //           thread -> (x = tid / KL (+ XR per pass), k4 = (tid % KL) * 4)
     // !KCONTIG: matrix stored [k][x], 16-byte vectors along x
-    //           thread -> (k = tid>>5 (+8), x4 = (tid&31)*4)
+    //           thread -> (k = tid >> 5 (+ 8 per pass), x4 = (tid & 31) * 4)
     // `fast` (block-uniform): the 128-wide x range is fully inside the matrix, vectors are aligned and
     // the row map is a plain leading dimension -> no per-element guards, no divisions in the k loop.
-    const float* base[2];   // fast path: per-thread base pointers (k = 0)
-    long long xoff[2];      // guarded KCONTIG path: row offset of x (or -1)
+    const float* base[NV];  // fast path: per-thread base pointers (k = 0)
+    long long xoff[NV];     // guarded KCONTIG path: row offset of x (or -1)
     long long kstride;      // fast !KCONTIG: elements between consecutive k rows
     bool fast;
 
@@ -38,33 +48,33 @@ struct TileLoader {
         if (KCONTIG) {
             fast = vec && (x0 + 128 <= X);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int x = x0 + (tid >> 2) + 64 * r;
+            for (int r = 0; r < NV; ++r) {
+                const int x = x0 + tid / KL + XR * r;
                 xoff[r] = (x < X) ? rm.off(x) : -1;
-                base[r] = P + (xoff[r] >= 0 ? xoff[r] : 0) + (tid & 3) * 4;
+                base[r] = P + (xoff[r] >= 0 ? xoff[r] : 0) + (tid % KL) * 4;
             }
             kstride = 1;
         } else {
             fast = vec && (x0 + 128 <= X) && (rm.rpg >= rows_k);
             kstride = rm.ld;
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < NV; ++r)
                 base[r] = P + (long long)((tid >> 5) + 8 * r) * rm.ld + x0 + (tid & 31) * 4;
         }
     }
 
-    __device__ inline void load(float4 (&v)[2], const float* __restrict__ P, const RowMap& rm, int x0, int X,
+    __device__ inline void load(float4 (&v)[NV], const float* __restrict__ P, const RowMap& rm, int x0, int X,
                                 int kt0, int kend, int tid, bool vec) const {
         if (fast && kt0 + BKT <= kend) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < NV; ++r)
                 v[r] = *reinterpret_cast<const float4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
             return;
         }
         if (KCONTIG) {
-            const int k = kt0 + (tid & 3) * 4;
+            const int k = kt0 + (tid % KL) * 4;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < NV; ++r) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (xoff[r] >= 0) {
                     const float* p = P + xoff[r] + k;
@@ -82,7 +92,7 @@ struct TileLoader {
         } else {
             const int x = x0 + (tid & 31) * 4;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < NV; ++r) {
                 const int k = kt0 + (tid >> 5) + 8 * r;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend && x < X) {
@@ -101,12 +111,12 @@ struct TileLoader {
         }
     }
 
-    __device__ inline void store(const float4 (&v)[2], float (*S)[LDT], int tid) const {
+    __device__ inline void store(const float4 (&v)[NV], float (*S)[LDT], int tid) const {
         if (KCONTIG) {
-            const int k4 = (tid & 3) * 4;
+            const int k4 = (tid % KL) * 4;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int x = (tid >> 2) + 64 * r;
+            for (int r = 0; r < NV; ++r) {
+                const int x = tid / KL + XR * r;
                 S[k4 + 0][x] = v[r].x;
                 S[k4 + 1][x] = v[r].y;
                 S[k4 + 2][x] = v[r].z;
@@ -115,7 +125,7 @@ struct TileLoader {
         } else {
             const int x4 = (tid & 31) * 4;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < NV; ++r) {
                 const int k = (tid >> 5) + 8 * r;
                 *reinterpret_cast<float4*>(&S[k][x4]) = v[r];
             }
@@ -153,7 +163,7 @@ __device__ inline void gemm_tile(const float* __restrict__ A, const RowMap& ra, 
     const int li = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BKT - 1) / BKT;
 
-    float4 ra0[2], rb0[2], ra1[2], rb1[2];          // tiles kt+1 and kt+2 in flight
+    float4 ra0[NV], rb0[NV], ra1[NV], rb1[NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
         la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA);
         lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB);
@@ -187,15 +197,15 @@ __device__ inline void gemm_tile(const float* __restrict__ A, const RowMap& ra, 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (colsum_out) {
-            const int cm = tid & 127, kh = (tid >> 7) * 8;
+            const int cm = tid & 127, kh = (tid >> 7) * (BKT / 2);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) csum += As[buf][kh + kk][cm];
+            for (int kk = 0; kk < BKT / 2; ++kk) csum += As[buf][kh + kk][cm];
         }
         if (kt + 1 < nkt) {
             la.store(ra1, As[buf ^ 1], tid);
             lb.store(rb1, Bs[buf ^ 1], tid);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) { ra1[r] = ra0[r]; rb1[r] = rb0[r]; }
+            for (int r = 0; r < NV; ++r) { ra1[r] = ra0[r]; rb1[r] = rb0[r]; }
         }
         __syncthreads();
     }
@@ -230,7 +240,7 @@ __device__ inline void gemm_tile(const float* __restrict__ A, const RowMap& ra, 
 }
 
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(
+__global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
     float* __restrict__ C, RowMap rc, const float* __restrict__ bias,
     int M, int N, int K, int kchunk, long long slab_stride, int accumulate, int vecA, int vecB) {
@@ -262,7 +272,7 @@ struct TnGroup {
     long long total_out;      // sum of M * (N + has_colsum)
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
+__global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
     int pi = 0;
@@ -347,7 +357,7 @@ extern "C" int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra_, const floa
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
     dim3 grid(cdiv(N, BN), cdiv(M, BM), 1);
     hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
-                       A, ra, B, rb, C, rc, bias, M, N, K, ((K + 15) / 16) * 16 + 16, 0LL, accumulate,
+                       A, ra, B, rb, C, rc, bias, M, N, K, ((K + BKT - 1) / BKT) * BKT + BKT, 0LL, accumulate,
                        (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -362,7 +372,7 @@ extern "C" int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra_, const floa
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
     dim3 grid(cdiv(N, BN), cdiv(M, BM), 1);
     hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream,
-                       A, ra, B, rb, C, rc, (const float*)nullptr, M, N, K, ((K + 15) / 16) * 16 + 16, 0LL,
+                       A, ra, B, rb, C, rc, (const float*)nullptr, M, N, K, ((K + BKT - 1) / BKT) * BKT + BKT, 0LL,
                        accumulate, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -389,7 +399,7 @@ extern "C" int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra_, const floa
         return XPS_E_WORKSPACE;
     }
     XPS_CHECK_ARG(aligned16(workspace), "workspace must be 16-byte aligned");
-    int kchunk = ((cdiv(K > 0 ? K : 1, splits) + 15) / 16) * 16;
+    int kchunk = ((cdiv(K > 0 ? K : 1, splits) + BKT - 1) / BKT) * BKT;
     float* slabs = reinterpret_cast<float*>(workspace);
     RowMap rs;
     rs.gs = 0; rs.ld = N; rs.rpg = 1 << 30;
@@ -435,7 +445,7 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         if (sp < 1) sp = 1;
         if (sp > 256) sp = 256;
         P.splits = sp;
-        P.kchunk = ((cdiv(q.K > 0 ? q.K : 1, sp) + 15) / 16) * 16;
+        P.kchunk = ((cdiv(q.K > 0 ? q.K : 1, sp) + BKT - 1) / BKT) * BKT;
         P.tiles_n = cdiv(q.N, BN);
         P.vecA = (int)map_vec_ok(q.A, P.ra);
         P.vecB = (int)map_vec_ok(q.B, P.rb);

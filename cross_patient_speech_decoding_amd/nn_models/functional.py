@@ -328,6 +328,20 @@ def _dist_sum_(t, group):
     return 1
 
 
+_ROWS_CACHE = {}
+
+
+def _global_rows(rows, group, device):
+    """Sum of the per-rank row counts (SyncBN denominator).  Shard sizes are fixed from step to step, so
+    the (host-synchronising) all-reduce happens once per (group, local size) and is cached."""
+    key = (id(group), int(rows))
+    if key not in _ROWS_CACHE:
+        cnt = torch.tensor([float(rows)], dtype=torch.float64, device=device)
+        _dist_sum_(cnt, group)
+        _ROWS_CACHE[key] = float(cnt.item())
+    return _ROWS_CACHE[key]
+
+
 class TemporalConvFn(torch.autograd.Function):
     """x (B, T, C) -> (T', B, F) time-major.  The strided convolution is ONE GEMM over
     window rows of x (row map: trial stride T*C, window stride s*C, K = k*C contiguous)
@@ -357,9 +371,7 @@ class TemporalConvFn(torch.autograd.Function):
             world = _dist_sum_(stats, group)
             count = float(rows)
             if world > 1:
-                cnt = torch.tensor([count], dtype=torch.float64, device=x.device)
-                _dist_sum_(cnt, group)
-                count = float(cnt.item())
+                count = _global_rows(rows, group, x.device)
             mean = torch.empty(F, dtype=_f32, device=x.device)
             rstd = torch.empty(F, dtype=_f32, device=x.device)
             call('xps_bn_finalize_f32', _ptr(stats), count, _ptr(mean), _ptr(rstd), _ptr(running_mean),
