@@ -174,6 +174,7 @@ def main():
     model = build_model(c).to(dev)
     if world > 1:
         model.temporal_conv.process_group = dist.group.WORLD
+        model.temporal_conv.global_batch = c['trials_per_gpu'] * world
     opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5, group=dist.group.WORLD if world > 1 else None)
     X, y = make_data(rank, c)
     X, y = X.to(dev), y.to(dev)                  # inputs resident in HBM before the timed region

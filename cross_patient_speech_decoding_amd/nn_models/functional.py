@@ -328,18 +328,15 @@ def _dist_sum_(t, group):
     return 1
 
 
-_ROWS_CACHE = {}
-
-
-def _global_rows(rows, group, device):
-    """Sum of the per-rank row counts (SyncBN denominator).  Shard sizes are fixed from step to step, so
-    the (host-synchronising) all-reduce happens once per (group, local size) and is cached."""
-    key = (id(group), int(rows))
-    if key not in _ROWS_CACHE:
-        cnt = torch.tensor([float(rows)], dtype=torch.float64, device=device)
-        _dist_sum_(cnt, group)
-        _ROWS_CACHE[key] = float(cnt.item())
-    return _ROWS_CACHE[key]
+def _global_rows(rows, group, device, global_trials, Tp):
+    """SyncBN denominator = rows summed over ranks.  When the caller knows the global trial count of this
+    batch (the trainer does: it shards the batch itself) no communication is needed; otherwise one small
+    host-synchronising all-reduce."""
+    if global_trials is not None:
+        return float(global_trials) * Tp
+    cnt = torch.tensor([float(rows)], dtype=torch.float64, device=device)
+    _dist_sum_(cnt, group)
+    return float(cnt.item())
 
 
 class TemporalConvFn(torch.autograd.Function):
@@ -350,7 +347,7 @@ class TemporalConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, gamma, beta, running_mean, running_var, stride, training,
-                relu, drop_mask, drop_scale, momentum, eps, group):
+                relu, drop_mask, drop_scale, momentum, eps, group, global_trials=None):
         _need_gpu(x, conv_w)
         x = x.contiguous()
         B, T, Cin = x.shape
@@ -371,7 +368,7 @@ class TemporalConvFn(torch.autograd.Function):
             world = _dist_sum_(stats, group)
             count = float(rows)
             if world > 1:
-                count = _global_rows(rows, group, x.device)
+                count = _global_rows(rows, group, x.device, global_trials, Tp)
             mean = torch.empty(F, dtype=_f32, device=x.device)
             rstd = torch.empty(F, dtype=_f32, device=x.device)
             call('xps_bn_finalize_f32', _ptr(stats), count, _ptr(mean), _ptr(rstd), _ptr(running_mean),
@@ -410,7 +407,7 @@ class TemporalConvFn(torch.autograd.Function):
         gemm_tn_grouped([tn_problem(dy, x, dw2, F, k * Cin, rows, ra=rowmap(B * F, rpg=Tp, gs=F),
                                     rb=rowmap(stride * Cin, rpg=Tp, gs=T * Cin), colsum_out=dconv_b)], dev)
         dconv_w = dw2.view(F, k, Cin).permute(0, 2, 1).contiguous()
-        return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 10
+        return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 11
 
 
 # --------------------------------------------------------------------------- #

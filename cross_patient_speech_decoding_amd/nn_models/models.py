@@ -84,6 +84,7 @@ class TemporalConv(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.activation = activation
         self.process_group = None        # set by the data-parallel trainer (SyncBN statistics)
+        self.global_batch = None         # trials of the current batch summed over ranks (set by the trainer)
 
     def forward_tm(self, x):
         k, s, pad = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
@@ -103,7 +104,7 @@ class TemporalConv(nn.Module):
         return XF.TemporalConvFn.apply(x, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
                                        self.bn.running_mean, self.bn.running_var, s, training,
                                        bool(self.activation), mask, scale, momentum, self.bn.eps,
-                                       self.process_group)
+                                       self.process_group, self.global_batch if self.process_group is not None else None)
 
     def forward(self, x):
         return self.forward_tm(x.permute(0, 2, 1)).permute(1, 2, 0)

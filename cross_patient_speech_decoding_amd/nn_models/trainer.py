@@ -222,6 +222,8 @@ class Trainer:
             for bi, (x, y) in enumerate(train_dataloaders):
                 n_global = x.shape[0]
                 x, y = _shard(x, rank, world).to(dev), _shard(y, rank, world).to(dev)
+                if hasattr(model, 'temporal_conv'):
+                    model.temporal_conv.global_batch = n_global
                 model._xps_logged = {}
                 self.optimizer.zero_grad()
                 loss = model.training_step((x, y), bi)

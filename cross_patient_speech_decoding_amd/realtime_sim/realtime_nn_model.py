@@ -1,0 +1,166 @@
+"""Realtime (streaming) CTC-RNN inference on MI355X — counterpart of the reference's
+realtime_sim/realtime_nn_model.py (StackedRNN :22, DenseClassifier :66, RealtimeRNNModel :93,
+forward :153, reformat_time_windows :172).  BASELINE config 5: per-step GRU inference captured in a
+hipGraph.
+
+Scope: inference (forward) with the reference's parameter names (``rnn.rnn.*``, ``h0``,
+``classifier.fc.*``) so reference checkpoints load; CTC training stays out of scope.
+
+* ``forward(x)``: the right-aligned sliding windows are never materialised — window w of trial b is the
+  contiguous ``win*C`` floats at ``x[b, w*stride]``, read by the input-projection GEMM through a row map;
+  the recurrence runs in the fused GRU kernel with the trainable ``h0``.
+* ``StreamingDecoder``: one 20 ms step (window -> L GRU cells -> Linear) recorded ONCE into a hipGraph on
+  static device buffers and replayed per step; the hidden state never leaves the device.
+"""
+import torch
+import torch.nn as nn
+
+from ..nn_models import functional as XF
+from ..nn_models._lightning import LightningModule
+from .._lib import rowmap
+
+
+class StackedRNN(nn.Module):
+    def __init__(self, input_size, hidden_size, n_layers, dropout=0.3, bidirectional=False):
+        super().__init__()
+        self.rnn = nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=n_layers,
+                          dropout=dropout if n_layers > 1 else 0, bidirectional=bidirectional, batch_first=True)
+
+
+class DenseClassifier(nn.Module):
+    def __init__(self, input_size, n_classes):
+        super().__init__()
+        self.fc = nn.Linear(input_size, n_classes)
+
+
+def _layer_params(rnn, layer, ndir):
+    out = []
+    for d in range(ndir):
+        sfx = f'_l{layer}' + ('_reverse' if d else '')
+        out.append(tuple(getattr(rnn, n + sfx) for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
+    return out
+
+
+class RealtimeRNNModel(LightningModule):
+    def __init__(self, input_size, hidden_size, n_layers, n_classes, dropout=0.3, win_size=14, stride=4,
+                 bidirectional=False, learning_rate=1e-3, decay_steps=100, weight_decay=1e-5, blank=0):
+        super().__init__()
+        self.hparams_ = dict(input_size=input_size, hidden_size=hidden_size, n_layers=n_layers, n_classes=n_classes,
+                             dropout=dropout, win_size=win_size, stride=stride, bidirectional=bidirectional,
+                             learning_rate=learning_rate, decay_steps=decay_steps, weight_decay=weight_decay,
+                             blank=blank)
+        self.rnn = StackedRNN(input_size, hidden_size, n_layers, dropout, bidirectional)
+        for name, param in self.rnn.named_parameters():
+            if 'weight_hh' in name:
+                nn.init.orthogonal_(param)
+            if 'weight_ih' in name:
+                nn.init.xavier_uniform_(param)
+        ndir = 2 if bidirectional else 1
+        self.h0 = nn.Parameter(torch.zeros(n_layers * ndir, 1, hidden_size))
+        nn.init.xavier_uniform_(self.h0)
+        self.classifier = DenseClassifier(hidden_size * ndir, n_classes)
+        with torch.no_grad():
+            self.classifier.fc.bias[:] = -2.0
+            self.classifier.fc.bias[blank] = 2.0
+        self.win_size, self.stride, self.blank = win_size, stride, blank
+
+    def n_windows(self, T):
+        return (T - self.win_size) // self.stride + 1
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x (B, T, C) -> logits (B, n_windows, n_classes)."""
+        rnn = self.rnn.rnn
+        ndir = 2 if rnn.bidirectional else 1
+        H, L = rnn.hidden_size, rnn.num_layers
+        x = x.contiguous()
+        B, T, Cc = x.shape
+        nw = self.n_windows(T)
+        K = self.win_size * Cc
+        if K != rnn.input_size:
+            raise ValueError(f'input_size {rnn.input_size} != win_size * channels = {K}')
+        inp, inp_dim = None, K
+        for l in range(L):
+            params = _layer_params(rnn, l, ndir)
+            gi = torch.empty(ndir, nw, B, 3 * H, dtype=torch.float32, device=x.device)
+            for d, (w_ih, _, b_ih, _) in enumerate(params):
+                if l == 0:      # window rows (b, w) -> time-major rows (w, b)
+                    XF.gemm_nt(x, w_ih.contiguous(), gi[d], nw * B, 3 * H, K, bias=b_ih,
+                               ra=rowmap(self.stride * Cc, rpg=nw, gs=T * Cc), rc=rowmap(B * 3 * H, rpg=nw, gs=3 * H))
+                else:
+                    XF.gemm_nt(inp, w_ih.contiguous(), gi[d], nw * B, 3 * H, inp_dim, bias=b_ih)
+            h0 = self.h0[l * ndir:(l + 1) * ndir].expand(-1, B, -1).contiguous()
+            y_ext = XF.GRURecurFn.apply(gi, h0, ndir, *[p[1] for p in params], *[p[3] for p in params])
+            inp, inp_dim = y_ext[1:nw + 1].contiguous(), ndir * H
+        logits = XF.linear(inp, self.classifier.fc.weight, self.classifier.fc.bias)     # (nw, B, C)
+        return logits.permute(1, 0, 2).contiguous()
+
+    def reformat_time_windows(self, x):
+        """(B, T, C) -> (B, n_windows, win*C) right-aligned windows (materialised; for inspection only)."""
+        B, T, Cc = x.shape
+        nw = self.n_windows(T)
+        idx = (torch.arange(nw, device=x.device) * self.stride)[:, None] + torch.arange(self.win_size, device=x.device)
+        return x[:, idx, :].reshape(B, nw, self.win_size * Cc)
+
+
+class StreamingDecoder:
+    """Per-step streaming inference with a hipGraph: ``step(window)`` runs one window (win*C floats per
+    stream) through all GRU layers and the classifier; the hidden state stays in static device buffers."""
+
+    def __init__(self, model, n_streams=1, use_graph=True):
+        rnn = model.rnn.rnn
+        if rnn.bidirectional:
+            raise ValueError('streaming decode needs a unidirectional model')
+        self.model, self.B = model, n_streams
+        self.H, self.L, self.K = rnn.hidden_size, rnn.num_layers, rnn.input_size
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('StreamingDecoder needs the model on the GPU (no CPU fallback)')
+        self.dev = dev
+        self.window = torch.zeros(self.B, self.K, dtype=torch.float32, device=dev)
+        self.h = torch.zeros(self.L, self.B, self.H, dtype=torch.float32, device=dev)
+        self.logits = torch.zeros(self.B, model.classifier.fc.out_features, dtype=torch.float32, device=dev)
+        self.token = torch.zeros(self.B, dtype=torch.int64, device=dev)
+        self._params = [_layer_params(rnn, l, 1)[0] for l in range(self.L)]
+        self._params = [tuple(p.detach().contiguous() for p in ps) for ps in self._params]
+        self._fc = (model.classifier.fc.weight.detach().contiguous(), model.classifier.fc.bias.detach().contiguous())
+        self.reset()
+        self.graph = None
+        if use_graph:
+            self._body()                             # warm-up (allocations, module load)
+            torch.cuda.synchronize()
+            self.reset()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graph = g
+            self.reset()
+
+    def reset(self):
+        with torch.no_grad():
+            self.h.copy_(self.model.h0.detach().expand(-1, self.B, -1))
+
+    @torch.no_grad()
+    def _body(self):
+        B, H = self.B, self.H
+        inp, k = self.window, self.K
+        for l, (w_ih, w_hh, b_ih, b_hh) in enumerate(self._params):
+            gi = torch.empty(1, 1, B, 3 * H, dtype=torch.float32, device=self.dev)
+            XF.gemm_nt(inp, w_ih, gi, B, 3 * H, k, bias=b_ih)
+            y_ext, _ = XF._gru_forward(gi, [w_hh], [b_hh], self.h[l:l + 1], 1, B, H, 1, False)
+            self.h[l].copy_(y_ext[1])
+            inp, k = self.h[l], H
+        XF.gemm_nt(inp, self._fc[0], self.logits, B, self.logits.shape[1], H, bias=self._fc[1])
+        self.token.copy_(XF.next_token(self.logits, None, None))
+
+    @torch.no_grad()
+    def step(self, window=None):
+        """window: (n_streams, win*C) device or host tensor (None: reuse the static buffer).  Returns the
+        static logits buffer (n_streams, n_classes); ``self.token`` holds the argmax class."""
+        if window is not None:
+            self.window.copy_(window.reshape(self.B, self.K), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+        return self.logits

@@ -36,6 +36,7 @@ def hip_step(rank, world, X, y, group):
     m.load_state_dict(weights_from_seed(m.state_dict(), 5))
     m = m.cuda().train()
     m.temporal_conv.process_group = group
+    m.temporal_conv.global_batch = X.shape[0] if group is not None else None
     opt = FlatAdamW(m, lr=1e-3, weight_decay=1e-5, max_norm=0.5, group=group)
     xs, ys = X[rank::world].cuda(), y[rank::world].cuda()
     opt.zero_grad()

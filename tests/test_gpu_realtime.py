@@ -1,0 +1,79 @@
+"""Config 5: realtime CTC-RNN inference on the GPU — full-sequence forward against the reference golden,
+hipGraph-captured per-step streaming against the full forward, greedy CTC decode."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from weights import weights_from_seed  # noqa: E402
+
+
+def build(g):
+    from cross_patient_speech_decoding_amd.realtime_sim import RealtimeRNNModel
+    C, win, stride, H, L, ncls = [int(v) for v in g['cfg']]
+    m = RealtimeRNNModel(win * C, H, L, ncls, dropout=0.0, win_size=win, stride=stride)
+    sd = weights_from_seed(m.state_dict(), int(g['seed']))
+    sd['h0'] = torch.from_numpy(g['h0'])
+    m.load_state_dict(sd)
+    return m.cuda().eval(), (C, win, stride, H, L, ncls)
+
+
+def test_forward_matches_reference_golden(golden_dir):
+    from cross_patient_speech_decoding_amd.realtime_sim import greedy_decode_batch
+    g = np.load(os.path.join(golden_dir, 'realtime_small.npz'))
+    m, _ = build(g)
+    x = torch.from_numpy(g['x']).cuda()
+    logits = m(x)
+    assert np.abs(logits.cpu().numpy() - g['logits']).max() <= 1e-4
+    np.testing.assert_array_equal(logits.argmax(-1).cpu().numpy(), g['logits'].argmax(-1))
+    dec = greedy_decode_batch(torch.log_softmax(logits, -1), blank=0)
+    for i, d in enumerate(dec):
+        np.testing.assert_array_equal(d.cpu().numpy(), g[f'dec{i}'])
+    w = m.reformat_time_windows(x)
+    assert w.shape == (3, 13, 14 * 6)
+    np.testing.assert_array_equal(w[1, 2].cpu().numpy(), g['x'][1, 8:22].reshape(-1))
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_streaming_steps_equal_full_forward(golden_dir, use_graph):
+    from cross_patient_speech_decoding_amd.realtime_sim import StreamingDecoder
+    g = np.load(os.path.join(golden_dir, 'realtime_small.npz'))
+    m, (C, win, stride, H, L, ncls) = build(g)
+    x = torch.from_numpy(g['x']).cuda()
+    full = m(x)                                         # (3, 13, 11)
+    dec = StreamingDecoder(m, n_streams=1, use_graph=use_graph)
+    for b in range(2):
+        dec.reset()
+        toks = []
+        for w in range(full.shape[1]):
+            window = x[b, w * stride:w * stride + win].reshape(1, -1)
+            lg = dec.step(window)
+            assert (lg[0] - full[b, w]).abs().max().item() <= 2e-5, (b, w)
+            toks.append(int(dec.token[0]))
+        assert toks == full[b].argmax(-1).tolist()
+
+
+def test_streaming_latency_budget():
+    """hipGraph replay of one 20 ms step (C = 128 channels -> 1792-wide window, H = 128, L = 2, batch 1).  The
+    reference reports 2.06 ms per prediction; the bar here is only that the graph path works at
+    the config-5 shape and is well under that."""
+    from cross_patient_speech_decoding_amd.realtime_sim import RealtimeRNNModel, StreamingDecoder
+    torch.manual_seed(0)
+    m = RealtimeRNNModel(14 * 128, 128, 2, 11, dropout=0.0).cuda().eval()
+    dec = StreamingDecoder(m, n_streams=1, use_graph=True)
+    win = torch.randn(1, 14 * 128, device='cuda')
+    for _ in range(20):
+        dec.step(win)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 200
+    for _ in range(n):
+        dec.step(win)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / n * 1e6
+    print(f'streaming step latency (graph replay, incl. window upload): {us:.1f} us')
+    assert us < 1000.0
