@@ -162,11 +162,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
+    # rehearsal knobs (1-GPU box): XPS_BENCH_BACKEND=gloo XPS_BENCH_ONE_DEVICE=1 put every rank on cuda:0
+    backend = os.environ.get('XPS_BENCH_BACKEND', 'nccl')
+    if os.environ.get('XPS_BENCH_ONE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
     c = CFG

@@ -58,6 +58,8 @@ SIGNATURES = {
     'xps_decoder_supported': (_i, [_i, _i, _i]),
     'xps_decoder_fwd_f32': (_i, [_vp] * 12 + [_i] * 6 + [_vp]),
     'xps_decoder_bwd_f32': (_i, [_vp] * 8 + [_i] * 4 + [_vp]),
+    'xps_gemv_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'xps_gru_cell_gemv_f32': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'xps_gather_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'xps_scatter_rows_f32_workspace': (_sz, [_i, _i, _i]),
     'xps_scatter_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -104,63 +104,88 @@ class RealtimeRNNModel(LightningModule):
 
 
 class StreamingDecoder:
-    """Per-step streaming inference with a hipGraph: ``step(window)`` runs one window (win*C floats per
-    stream) through all GRU layers and the classifier; the hidden state stays in static device buffers."""
+    """Per-step streaming inference replayed from a hipGraph: ``step(window)`` runs one window (win*C
+    floats per stream, 1..8 streams) through all GRU layers and the classifier with the weight-streaming
+    GEMV kernels (xps_gru_cell_gemv_f32: one launch per layer, xps_gemv_f32 for the classifier); the
+    hidden state lives in two static device buffers that alternate between steps (two captured graphs)."""
 
     def __init__(self, model, n_streams=1, use_graph=True):
+        from .._lib import call
         rnn = model.rnn.rnn
         if rnn.bidirectional:
             raise ValueError('streaming decode needs a unidirectional model')
+        if not 1 <= n_streams <= 8:
+            raise ValueError('1..8 streams per decoder')
         self.model, self.B = model, n_streams
         self.H, self.L, self.K = rnn.hidden_size, rnn.num_layers, rnn.input_size
         dev = next(model.parameters()).device
         if dev.type != 'cuda':
             raise RuntimeError('StreamingDecoder needs the model on the GPU (no CPU fallback)')
-        self.dev = dev
-        self.window = torch.zeros(self.B, self.K, dtype=torch.float32, device=dev)
-        self.h = torch.zeros(self.L, self.B, self.H, dtype=torch.float32, device=dev)
-        self.logits = torch.zeros(self.B, model.classifier.fc.out_features, dtype=torch.float32, device=dev)
-        self.token = torch.zeros(self.B, dtype=torch.int64, device=dev)
-        self._params = [_layer_params(rnn, l, 1)[0] for l in range(self.L)]
-        self._params = [tuple(p.detach().contiguous() for p in ps) for ps in self._params]
+        self.dev, self._call = dev, call
+        S = 1 << (n_streams - 1).bit_length()                 # rows allocated: power of two >= B
+        self.n_classes = model.classifier.fc.out_features
+        self.window = torch.zeros(S, self.K, dtype=torch.float32, device=dev)
+        self.hbuf = torch.zeros(2, self.L, S, self.H, dtype=torch.float32, device=dev)    # ping-pong state
+        self._logits = torch.zeros(S, self.n_classes, dtype=torch.float32, device=dev)
+        self._token = torch.zeros(S, dtype=torch.int64, device=dev)
+        self._params = [tuple(p.detach().contiguous() for p in _layer_params(rnn, l, 1)[0]) for l in range(self.L)]
         self._fc = (model.classifier.fc.weight.detach().contiguous(), model.classifier.fc.bias.detach().contiguous())
+        self.parity = 0
+        self.graphs = None
         self.reset()
-        self.graph = None
         if use_graph:
-            self._body()                             # warm-up (allocations, module load)
+            for par in (0, 1):                                # warm-up: module load, allocator
+                self._body(par)
             torch.cuda.synchronize()
+            self.graphs = []
+            for par in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body(par)
+                self.graphs.append(g)
             self.reset()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._body()
-            self.graph = g
-            self.reset()
+
+    @property
+    def logits(self):
+        return self._logits[:self.B]
+
+    @property
+    def token(self):
+        return self._token[:self.B]
+
+    @property
+    def h(self):
+        return self.hbuf[self.parity, :, :self.B]
 
     def reset(self):
         with torch.no_grad():
-            self.h.copy_(self.model.h0.detach().expand(-1, self.B, -1))
+            self.hbuf.zero_()
+            self.hbuf[:, :, :self.B] = self.model.h0.detach().expand(-1, self.B, -1)
+        self.parity = 0
 
     @torch.no_grad()
-    def _body(self):
-        B, H = self.B, self.H
+    def _body(self, par):
+        st = torch.cuda.current_stream().cuda_stream
+        src, dst = self.hbuf[par], self.hbuf[par ^ 1]
         inp, k = self.window, self.K
         for l, (w_ih, w_hh, b_ih, b_hh) in enumerate(self._params):
-            gi = torch.empty(1, 1, B, 3 * H, dtype=torch.float32, device=self.dev)
-            XF.gemm_nt(inp, w_ih, gi, B, 3 * H, k, bias=b_ih)
-            y_ext, _ = XF._gru_forward(gi, [w_hh], [b_hh], self.h[l:l + 1], 1, B, H, 1, False)
-            self.h[l].copy_(y_ext[1])
-            inp, k = self.h[l], H
-        XF.gemm_nt(inp, self._fc[0], self.logits, B, self.logits.shape[1], H, bias=self._fc[1])
-        self.token.copy_(XF.next_token(self.logits, None, None))
+            self._call('xps_gru_cell_gemv_f32', inp.data_ptr(), k, w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(),
+                       b_hh.data_ptr(), src[l].data_ptr(), dst[l].data_ptr(), self.H, self.B, st)
+            inp, k = dst[l], self.H
+        self._call('xps_gemv_f32', inp.data_ptr(), self._fc[0].data_ptr(), self._fc[1].data_ptr(), self._logits.data_ptr(),
+                   self.n_classes, self.H, self.B, st)
+        self._call('xps_next_token', self._logits.data_ptr(), self.n_classes, None, 0, None, self._token.data_ptr(),
+                   self.B, st)
 
     @torch.no_grad()
     def step(self, window=None):
         """window: (n_streams, win*C) device or host tensor (None: reuse the static buffer).  Returns the
-        static logits buffer (n_streams, n_classes); ``self.token`` holds the argmax class."""
+        logits (n_streams, n_classes) in a static buffer; ``self.token`` holds the argmax class."""
         if window is not None:
-            self.window.copy_(window.reshape(self.B, self.K), non_blocking=True)
-        if self.graph is not None:
-            self.graph.replay()
+            self.window[:self.B].copy_(window.reshape(self.B, self.K), non_blocking=True)
+        if self.graphs is not None:
+            self.graphs[self.parity].replay()
         else:
-            self._body()
+            self._body(self.parity)
+        self.parity ^= 1
         return self.logits

@@ -173,6 +173,15 @@ int xps_decoder_bwd_f32(const float* dlogits, const float* hs, const float* save
                         const float* w_fc, float* dgi, float* dghn, float* dh0,
                         int B, int H, int C, int L, void* stream);
 
+/* Streaming (batch-1 .. 8 streams) inference for the realtime decoder (realtime_sim/realtime_nn_model.py
+ * :153-170, one window per call): weight-streaming GEMV kernels, one wave per output row.
+ *   x, h_prev, h_new, out are [S][.] with S = 1, 2, 4 or 8 rows ALLOCATED (S = B rounded up to a power
+ *   of two); only the first B rows are written.  h_new must not alias h_prev.                       */
+int xps_gemv_f32(const float* x, const float* W, const float* bias, float* out, int N, int K, int B,
+                 void* stream);
+int xps_gru_cell_gemv_f32(const float* x, int K, const float* w_ih, const float* w_hh, const float* b_ih,
+                          const float* b_hh, const float* h_prev, float* h_new, int H, int B, void* stream);
+
 /* out[b][:] = table[idx[b]][:]  (embedding / precomputed input projection rows) */
 int xps_gather_rows_f32(const float* table, const int64_t* idx, float* out,
                         int B, int cols, int n_rows, void* stream);

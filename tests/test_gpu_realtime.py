@@ -55,6 +55,11 @@ def test_streaming_steps_equal_full_forward(golden_dir, use_graph):
             assert (lg[0] - full[b, w]).abs().max().item() <= 2e-5, (b, w)
             toks.append(int(dec.token[0]))
         assert toks == full[b].argmax(-1).tolist()
+    # three streams at once (rows padded to 4)
+    dec3 = StreamingDecoder(m, n_streams=3, use_graph=use_graph)
+    for w in range(full.shape[1]):
+        lg = dec3.step(x[:, w * stride:w * stride + win].reshape(3, -1))
+        assert (lg - full[:, w]).abs().max().item() <= 2e-5
 
 
 def test_streaming_latency_budget():
