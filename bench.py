@@ -155,6 +155,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--hidden', type=int, default=None, help='(exploration only) override the hidden size, e.g. 512 = cfg 4')
+    ap.add_argument('--channels', type=int, default=None, help='(exploration only) override the input channels')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -176,7 +178,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
-    c = CFG
+    c = dict(CFG)
+    if args.hidden:
+        c['hidden_size'] = args.hidden
+    if args.channels:
+        c['in_channels'] = args.channels
+    explore = bool(args.hidden or args.channels)
     torch.manual_seed(1234)                      # identical initial weights on every rank
     model = build_model(c).to(dev)
     if world > 1:
@@ -232,8 +239,11 @@ def main():
                        'parallelism': f'dp{world}', 'train_mflop_per_trial': round(fl / 1e6, 2)},
             'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
         }
-        out['roofline'] = time_dominant_kernel(model, c)
-        if world == 1 and not args.no_cpu_baseline:
+        if not explore:
+            out['roofline'] = time_dominant_kernel(model, c)
+        else:
+            out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
+        if world == 1 and not args.no_cpu_baseline and not explore:
             out['cpu_baseline'] = cpu_baseline(c)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
 }
 
 struct GruBwdParams {
-    const float* dy;
+    const float* dhn;       // (ndir x B x H) gradient w.r.t. the FINAL hidden state of each direction, or null
+    const float* dy;        // (T x B x ndir*H) gradient w.r.t. every step's output, or null
     const float* y_ext;
     const float* saved;
     const float* w_hh_t[2];
@@ -185,6 +186,13 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
 
     for (int i = tid; i < GBM * (ldg + ldc); i += 256) lds[i] = 0.f;
     __syncthreads();
+    if (p.dhn) {
+        for (int i = tid; i < GBM * H; i += 256) {
+            const int r = i / H, k = i % H, b = b0 + r;
+            if (b < B) Cy[r * ldc + k] = p.dhn[((long long)dir * B + b) * H + k];
+        }
+        __syncthreads();
+    }
 
     const int ntile = Hp / 16;
     for (int s = T - 1; s >= 0; --s) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
             const int r = idx / Hp, j = idx % Hp, b = b0 + r;
             float dar = 0.f, daz = 0.f, danr = 0.f, keep = 0.f;
             if (b < B && j < H) {
-                const float dh = p.dy[((long long)t * B + b) * ldy + dir * H + j] + Cy[r * ldc + j];
+                const float dh = (p.dy ? p.dy[((long long)t * B + b) * ldy + dir * H + j] : 0.f) + Cy[r * ldc + j];
                 const float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H;
                 const float rg = sv[j], zg = sv[H + j], ng = sv[2 * H + j], q = sv[3 * H + j];
                 const float hp = p.y_ext[((long long)slot_prev * B + b) * ldy + dir * H + j];
@@ -491,6 +499,13 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
     for (int i = tid; i < GBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
     for (int i = tid; i < GBM * LDC; i += 256) (&Cy[0][0])[i] = 0.f;
     __syncthreads();
+    if (p.dhn) {
+        for (int i = tid; i < GBM * H; i += 256) {
+            const int r = i / H, k = i % H, b = b0 + r;
+            if (b < B) Cy[r][k] = p.dhn[((long long)dir * B + b) * H + k];
+        }
+        __syncthreads();
+    }
 
     // inputs of the gate-gradient phase for one step: saved r,z,n,q, h_prev and dy (7 x float4 per group)
     struct StepIn { float4 dy, rg, zg, ng, q, hp; };
@@ -505,7 +520,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
             int b = b0 + r;
             b = b < B ? b : B - 1;
             const float* sv = p.saved + (((long long)dir * T + t_) * B + b) * 4 * H;
-            dst[e].dy = *reinterpret_cast<const float4*>(p.dy + ((long long)t_ * B + b) * ldy + dir * H + j);
+            dst[e].dy = p.dy ? *reinterpret_cast<const float4*>(p.dy + ((long long)t_ * B + b) * ldy + dir * H + j)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
             dst[e].rg = *reinterpret_cast<const float4*>(sv + j);
             dst[e].zg = *reinterpret_cast<const float4*>(sv + H + j);
             dst[e].ng = *reinterpret_cast<const float4*>(sv + 2 * H + j);
@@ -670,14 +686,15 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     return XPS_OK;
 }
 
-extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const float* saved,
+extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                    const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                                    int T, int B, int H, int ndir, void* stream) {
-    XPS_CHECK_ARG(dy && y_ext && saved && w_hh_t && dgi && dghn, "null argument");
+    XPS_CHECK_ARG(y_ext && saved && w_hh_t && dgi && dghn, "null argument");
+    XPS_CHECK_ARG(dy || dhn, "at least one of dy / dhn must be given");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
     GruBwdParams p;
-    p.dy = dy; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
+    p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;
     p.Hp = ((H + 15) / 16) * 16;
     p.ldg = 3 * p.Hp + 4;

@@ -214,6 +214,38 @@ __global__ void mask_scale_kernel(const float* __restrict__ x, const float* __re
         out[i] = x[i] * mask[i] * scale;
 }
 
+// counter-based RNG (splitmix64 finaliser over seed + element-pair index): two 24-bit uniforms per hash
+__device__ inline void rng_pair(unsigned long long seed, long long pair, float& u0, float& u1) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(pair + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    u0 = (float)((unsigned)(z >> 40)) * (1.0f / 16777216.0f);
+    u1 = (float)((unsigned)(z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+
+// mask[i] = (u_i >= p); optionally out[i] = x[i] * mask[i] * scale in the same pass
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ mask,
+                               long long n, float p, float scale, unsigned long long seed) {
+    const long long npair = (n + 1) / 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < npair; q += (long long)gridDim.x * blockDim.x) {
+        float u0, u1;
+        rng_pair(seed, q, u0, u1);
+        const long long i = 2 * q;
+        const float m0 = u0 >= p ? 1.f : 0.f, m1 = u1 >= p ? 1.f : 0.f;
+        if (i + 1 < n) {
+            *reinterpret_cast<float2*>(mask + i) = make_float2(m0, m1);
+            if (x) {
+                const float2 v = *reinterpret_cast<const float2*>(x + i);
+                *reinterpret_cast<float2*>(out + i) = make_float2(v.x * m0 * scale, v.y * m1 * scale);
+            }
+        } else {
+            mask[i] = m0;
+            if (x) out[i] = x[i] * m0 * scale;
+        }
+    }
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         out[i] = a[i] + b[i];
@@ -471,6 +503,18 @@ extern "C" int xps_mask_scale_f32(const float* x, const float* mask, float scale
     if (n == 0) return XPS_OK;
     hipLaunchKernelGGL(mask_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, out,
                        (long long)n);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_dropout_f32(const float* x, float* out, float* mask, int64_t n, float p, uint64_t seed, void* stream) {
+    XPS_CHECK_ARG(mask && n >= 0 && p >= 0.f && p < 1.f, "bad argument");
+    XPS_CHECK_ARG((x == nullptr) == (out == nullptr), "x and out must both be given or both NULL");
+    XPS_CHECK_ARG(((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 7) == 0,
+                  "buffers must be 8-byte aligned");
+    if (n == 0) return XPS_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, x, out, mask,
+                       (long long)n, p, 1.0f / (1.0f - p), (unsigned long long)seed);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

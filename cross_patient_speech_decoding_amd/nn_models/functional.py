@@ -183,23 +183,22 @@ def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save):
     return y_ext, saved
 
 
-def _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
-    """BPTT kernel.  Returns dgi (ndir,T,B,3H), dghn (ndir,T,B,H), dh0."""
+def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
+    """BPTT kernel.  dy (T,B,ndir*H) or None, dhn (ndir,B,H) or None.  Returns dgi (ndir,T,B,3H),
+    dghn (ndir,T,B,H), dh0 (ndir,B,H) or None."""
     dev = y_ext.device
-    dy = dy_ext[1:T + 1]
-    if not dy.is_contiguous():
+    if dy is not None and not dy.is_contiguous():
         dy = dy.contiguous()
+    if dhn is not None and not dhn.is_contiguous():
+        dhn = dhn.contiguous()
+    if dy is None and dhn is None:
+        dhn = torch.zeros(ndir, B, H, dtype=_f32, device=dev)
     w_t = [transpose(w, 3 * H, H) for w in w_hh]
     dgi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
     dghn = torch.empty(ndir, T, B, H, dtype=_f32, device=dev)
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
-    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(y_ext), _ptr(saved), _ptr_array(w_t), _ptr(dgi), _ptr(dghn),
+    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_t), _ptr(dgi), _ptr(dghn),
          _ptr(dh0), T, B, H, ndir, _stream())
-    if need_dh0:
-        # gradient that arrived directly on the h0 slots of y_ext
-        dh0[0] += dy_ext[0, :, :H]
-        if ndir == 2:
-            dh0[1] += dy_ext[T + 1, :, H:]
     return dgi, dghn, dh0
 
 
@@ -252,8 +251,12 @@ class GRURecurFn(torch.autograd.Function):
     def backward(ctx, dy_ext):
         y_ext, saved, *w_hh = ctx.saved_tensors
         T, B, H, ndir = ctx.dims
-        dgi, dghn, dh0 = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir,
-                                       ctx.has_h0 and ctx.needs_input_grad[1])
+        need_dh0 = ctx.has_h0 and ctx.needs_input_grad[1]
+        dgi, dghn, dh0 = _gru_backward(dy_ext[1:T + 1], None, y_ext, saved, w_hh, T, B, H, ndir, need_dh0)
+        if need_dh0:                                   # gradient that arrived directly on the h0 slots of y_ext
+            dh0[0] += dy_ext[0, :, :H]
+            if ndir == 2:
+                dh0[1] += dy_ext[T + 1, :, H:]
         probs, rets = _recurrent_grad_problems(dgi, dghn, y_ext, ctx.params[:ndir], ctx.params[ndir:], T, B, H, ndir)
         gemm_tn_grouped(probs, y_ext.device)
         return (dgi, dh0, None, *[r[0] for r in rets], *[r[1] for r in rets])
@@ -262,10 +265,12 @@ class GRURecurFn(torch.autograd.Function):
 class GRULayerFn(torch.autograd.Function):
     """One (bi)directional GRU layer over a time-major input x (T, B, In):
     input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel + ONE grouped
-    launch for all six weight/bias gradients.  weights: per direction (w_ih, w_hh, b_ih, b_hh)."""
+    launch for all six weight/bias gradients.  weights: per direction (w_ih, w_hh, b_ih, b_hh).
+    Returns (y (T, B, ndir*H), hn (ndir, B, H))."""
 
     @staticmethod
     def forward(ctx, x, ndir, *wb):
+        ctx.set_materialize_grads(False)
         _need_gpu(x, *wb)
         x = x.contiguous()
         T, B, In = x.shape
@@ -283,15 +288,20 @@ class GRULayerFn(torch.autograd.Function):
             ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
         ctx.params = wb
         ctx.dims = (T, B, H, ndir, In)
-        return y_ext
+        # y: per-step outputs (a view of y_ext: slots 1..T); hn: final hidden state of each direction
+        # (forward: t = T-1, reverse: t = 0), returned separately so that a consumer of the final state
+        # only (the seq2seq encoder) sends back a (ndir, B, H) gradient instead of a zero-padded (T, B, .) one
+        y = y_ext[1:T + 1]
+        hn = torch.stack([y_ext[T, :, :H]] + ([y_ext[1, :, H:]] if ndir == 2 else []), dim=0)
+        return y, hn
 
     @staticmethod
-    def backward(ctx, dy_ext):
+    def backward(ctx, dy, dhn):
         T, B, H, ndir, In = ctx.dims
         x, y_ext, saved, *w = ctx.saved_tensors
         w_ih, w_hh = w[:ndir], w[ndir:]
         wb = ctx.params
-        dgi, dghn, _ = _gru_backward(dy_ext, y_ext, saved, w_hh, T, B, H, ndir, False)
+        dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False)
         dev = x.device
         dx = None
         if ctx.needs_input_grad[0]:
@@ -554,13 +564,50 @@ class MaskScaleFn(torch.autograd.Function):
         return dx, None, None
 
 
+_DROP_COUNTER = [0]
+
+
+def next_dropout_seed():
+    """64-bit seed for one dropout site: drawn from torch's CPU generator on first use (so
+    torch.manual_seed governs the run), then advanced by a fixed odd stride per call."""
+    if _DROP_COUNTER[0] == 0:
+        _DROP_COUNTER[0] = int(torch.randint(1, 2 ** 62, (1,)).item()) | 1
+    _DROP_COUNTER[0] = (_DROP_COUNTER[0] + 0x9E3779B97F4A7C15) % (2 ** 64)
+    return _DROP_COUNTER[0]
+
+
+def dropout_mask(shape, p, device):
+    """{0,1} float mask with P(0) = p from the in-kernel counter-based generator (one pass, no torch RNG
+    kernels)."""
+    mask = torch.empty(shape, dtype=_f32, device=device)
+    call('xps_dropout_f32', None, None, _ptr(mask), mask.numel(), float(p), next_dropout_seed(), _stream())
+    return mask
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        out, mask = torch.empty_like(x), torch.empty_like(x)
+        call('xps_dropout_f32', _ptr(x), _ptr(out), _ptr(mask), x.numel(), float(p), next_dropout_seed(), _stream())
+        ctx.save_for_backward(mask)
+        ctx.scale = 1.0 / (1.0 - p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.empty_like(dout)
+        call('xps_mask_scale_f32', _ptr(dout), _ptr(mask), ctx.scale, _ptr(dx), dout.numel(), _stream())
+        return dx, None
+
+
 def dropout(x, p, training):
-    """Inverted dropout; the Bernoulli mask comes from torch's device RNG (so
-    torch.manual_seed governs it), the multiply is the HIP kernel."""
+    """Inverted dropout, mask generation and multiply fused in one HIP pass."""
     if not training or p <= 0.0:
         return x
-    mask = (torch.rand_like(x) >= p).to(_f32)
-    return MaskScaleFn.apply(x, mask, 1.0 / (1.0 - p))
+    return DropoutFn.apply(x, p)
 
 
 class CrossEntropyFn(torch.autograd.Function):

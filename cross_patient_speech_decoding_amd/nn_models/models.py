@@ -96,7 +96,7 @@ class TemporalConv(nn.Module):
         training = self.training
         mask, scale, p = None, 1.0, self.dropout.p
         if training and p > 0:
-            mask = (torch.rand(Tp, B, F, device=x.device) >= p).to(torch.float32)
+            mask = XF.dropout_mask((Tp, B, F), p, x.device)
             scale = 1.0 / (1.0 - p)
         if training and self.bn.track_running_stats:
             self.bn.num_batches_tracked += 1
@@ -142,11 +142,10 @@ class EncoderRNN(nn.Module):
         T = x.shape[0]
         y = x
         for l in range(L):
-            y_ext = XF.GRULayerFn.apply(y, 2, *_gru_layer_weights(rnn, l, 2))
-            y = y_ext[1:T + 1]
+            y, hn = XF.GRULayerFn.apply(y, 2, *_gru_layer_weights(rnn, l, 2))
             if l < L - 1:
                 y = XF.dropout(y, rnn.dropout, self.training)
-        last = y_ext[T, :, :H] + y_ext[1, :, H:]          # h_fwd(T-1) + h_bwd(0)
+        last = hn[0] + hn[1]                              # h_fwd(T-1) + h_bwd(0)
         return y, last.unsqueeze(0)
 
     def forward(self, x):

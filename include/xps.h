@@ -109,13 +109,16 @@ int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* 
                         int T, int B, int H, int ndir, void* stream);
 
 /* Backward through the recurrence (BPTT).
- *   dy     [T][B][ndir*H]   gradient w.r.t. the layer output (actual time)
+ *   dy     [T][B][ndir*H]   gradient w.r.t. the layer output (actual time), or NULL (all zero)
+ *   dhn    [ndir][B][H]     gradient w.r.t. the FINAL hidden state of each direction (h at t = T-1 forward,
+ *                           t = 0 reverse), or NULL; it seeds the running dh, so a layer whose per-step
+ *                           output is unused downstream needs no dy buffer at all
  *   w_hh_t [ndir] pointers to W_hh^T (H x 3H), see xps_transpose_f32
  *   dgi    [ndir][T][B][3H] gradient w.r.t. gi   (= w.r.t. input pre-activations r, z, n)
  *   dghn   [ndir][T][B][H]  n-gate part of the gradient w.r.t. (h_{t-1} W_hh^T + b_hh); its r and z
  *                           parts equal those of dgi, so they are not stored twice
  *   dh0    [ndir][B][H]     gradient w.r.t. h0 (or NULL)                       */
-int xps_gru_seq_bwd_f32(const float* dy, const float* y_ext, const float* saved,
+int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                         const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                         int T, int B, int H, int ndir, void* stream);
 
@@ -195,6 +198,10 @@ int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float* dtable,
  * decode loop has no host synchronisation.                                     */
 int xps_next_token(const float* logits, int n_classes, const int64_t* teacher, int64_t teacher_stride,
                    const int32_t* use_teacher, int64_t* next, int B, void* stream);
+/* Inverted dropout with a counter-based generator (no mask round trip through torch's RNG kernels):
+ * mask[i] = (u_i >= p) in {0,1}, u_i a function of (seed, i) only;  if x != NULL also
+ * out[i] = x[i] * mask[i] / (1 - p) in the same pass.  The backward is xps_mask_scale_f32.          */
+int xps_dropout_f32(const float* x, float* out, float* mask, int64_t n, float p, uint64_t seed, void* stream);
 /* out = x * mask * scale */
 int xps_mask_scale_f32(const float* x, const float* mask, float scale, float* out, int64_t n, void* stream);
 /* out = a + b (elementwise) */

@@ -130,13 +130,9 @@ def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir):
     xf = XF()
     ws = [dev(w).requires_grad_(True) for w in _weights(gru, ndir)]
     xg = dev(x).requires_grad_(True)
-    y_ext = xf.GRULayerFn.apply(xg, ndir, *ws)
-    y = y_ext[1:T + 1]
+    y, hn = xf.GRULayerFn.apply(xg, ndir, *ws)
     np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5)
-    # h_n of each direction lives in y_ext: fwd at slot T, reverse at slot 1
-    np.testing.assert_allclose(y_ext[T, :, :H].detach().cpu().numpy(), hn_ref[0].detach().numpy(), atol=2e-5)
-    if ndir == 2:
-        np.testing.assert_allclose(y_ext[1, :, H:].detach().cpu().numpy(), hn_ref[1].detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), hn_ref.detach().numpy(), atol=2e-5)
     (y * dev(wt)).sum().backward()
     np.testing.assert_allclose(xg.grad.cpu().numpy(), x_ref.grad.numpy(), atol=5e-5, rtol=1e-4)
     names = []
@@ -147,6 +143,46 @@ def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir):
         ref = getattr(gru, n).grad.numpy()
         tol = 2e-4 * max(1.0, float(np.abs(ref).max()))
         np.testing.assert_allclose(w.grad.cpu().numpy(), ref, atol=tol, rtol=1e-3, err_msg=n)
+
+
+def test_gru_layer_final_state_gradient_only():
+    """Only h_n is consumed (the seq2seq encoder's top layer): the backward gets dhn and NO dy buffer."""
+    torch.set_num_threads(4)
+    T, B, In, H = 6, 19, 10, 64
+    gru = _cpu_gru(In, H, 2, seed=11)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(T, B, In, generator=g)
+    wt = torch.randn(2, B, H, generator=g)
+    x_ref = x.clone().requires_grad_(True)
+    _, hn_ref = gru(x_ref)
+    (hn_ref * wt).sum().backward()
+    xf = XF()
+    ws = [dev(w).requires_grad_(True) for w in _weights(gru, 2)]
+    xg = dev(x).requires_grad_(True)
+    _, hn = xf.GRULayerFn.apply(xg, 2, *ws)
+    (hn * dev(wt)).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x_ref.grad.numpy(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(ws[1].grad.cpu().numpy(), gru.weight_hh_l0.grad.numpy(), atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(ws[4].grad.cpu().numpy(), gru.weight_ih_l0_reverse.grad.numpy(), atol=1e-4, rtol=1e-3)
+
+
+def test_dropout_kernel_statistics_and_backward():
+    xf = XF()
+    x = torch.randn(64, 1000, device='cuda').requires_grad_(True)
+    torch.manual_seed(3)
+    out = xf.dropout(x, 0.3, True)
+    keep = (out != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    nz = out != 0
+    np.testing.assert_allclose(out[nz].detach().cpu().numpy(), (x[nz] / 0.7).detach().cpu().numpy(), rtol=1e-6)
+    out.sum().backward()
+    np.testing.assert_allclose(x.grad[nz].cpu().numpy(), 1 / 0.7, rtol=1e-6)
+    assert (x.grad[~nz] == 0).all()
+    out2 = xf.dropout(x, 0.3, True)                   # a new call draws a new mask
+    assert ((out2 != 0) != nz).float().mean().item() > 0.2
+    m = xf.dropout_mask((257, 33), 0.5, 'cuda')        # odd element count
+    assert set(m.unique().tolist()) <= {0.0, 1.0} and abs(m.mean().item() - 0.5) < 0.02
+    assert xf.dropout(x, 0.3, False) is x
 
 
 def test_gru_recurrence_with_h0_and_dh0():

@@ -16,6 +16,6 @@ for _ in range(10):
     if which == 'fwd':
         XF._gru_forward(gi, w_hh, b_hh, None, T, B, H, 2, True)
     else:
-        XF._gru_backward(dy, y_ext, saved, w_hh, T, B, H, 2, False)
+        XF._gru_backward(dy[1:T + 1], None, y_ext, saved, w_hh, T, B, H, 2, False)
 torch.cuda.synchronize()
 print('done')
