@@ -139,10 +139,18 @@ def time_dominant_kernel(model, c):
     gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
     dur_gru = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True))
     fl_gru = 2 * Tp * B * 2 * 3 * H * H
+    # HBM traffic of this launch from the PMC counters (collected offline with rocprofv3 --pmc, separate passes,
+    # gfx950 FETCH_SIZE correction applied): profiles/round1/pmc_traffic.json
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'round1', 'pmc_traffic.json')) as f:
+            traffic = json.load(f)['gemm_tn_grouped_kernel']['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
     return {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel (fp32 MFMA 128x128x16 tile; encoder layer-1 weight '
                                        'gradients, 6 problems in one launch, incl. its reduce pass)',
             'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
             'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops,
             'also': {'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions)',
                      'achieved': round(fl_gru / dur_gru / 1e12, 3), 'frac': round(fl_gru / dur_gru / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
