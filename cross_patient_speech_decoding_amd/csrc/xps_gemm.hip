@@ -27,26 +27,27 @@ namespace {
 #endif
 constexpr int BM = 128, BN = 128, BKT = XPS_BKT, LDT = 132;
 
-constexpr int NV = BKT / 8;          // 16-byte vectors per thread, operand and k-tile
 constexpr int KL = BKT / 4;          // KCONTIG: lanes covering one row's k range
-constexpr int XR = 256 / KL;         // KCONTIG: rows of x covered per pass
 
-template <bool KCONTIG>
+// Stages a (BKT x W) k-major tile of a matrix stored either [x][k] (KCONTIG) or [k][x]; W = 64 or 128.
+template <bool KCONTIG, int W>
 struct TileLoader {
-    // KCONTIG : matrix stored [x][k]  (x = m or n), 16-byte vectors along k
-    //           thread -> (x = tid / KL (+ XR per pass), k4 = (tid % KL) * 4)
-    // !KCONTIG: matrix stored [k][x], 16-byte vectors along x
-    //           thread -> (k = tid >> 5 (+ 8 per pass), x4 = (tid & 31) * 4)
-    // `fast` (block-uniform): the 128-wide x range is fully inside the matrix, vectors are aligned and
+    // KCONTIG : 16-byte vectors along k; thread -> (x = tid / KL (+ XR per pass), k4 = (tid % KL) * 4)
+    // !KCONTIG: 16-byte vectors along x; thread -> (k = tid / XL (+ KR per pass), x4 = (tid % XL) * 4)
+    // `fast` (block-uniform): the W-wide x range is fully inside the matrix, vectors are aligned and
     // the row map is a plain leading dimension -> no per-element guards, no divisions in the k loop.
-    const float* base[NV];  // fast path: per-thread base pointers (k = 0)
-    long long xoff[NV];     // guarded KCONTIG path: row offset of x (or -1)
-    long long kstride;      // fast !KCONTIG: elements between consecutive k rows
+    static constexpr int XR = 256 / KL;                 // KCONTIG: x rows per pass
+    static constexpr int XL = W / 4;                    // !KCONTIG: lanes per k row
+    static constexpr int KR = 256 / XL;                 // !KCONTIG: k rows per pass
+    static constexpr int NV = KCONTIG ? W / XR : BKT / KR;
+    const float* base[NV];
+    long long xoff[NV];
+    long long kstride;
     bool fast;
 
     __device__ inline void init(const float* __restrict__ P, const RowMap& rm, int x0, int X, int rows_k, int tid, bool vec) {
         if (KCONTIG) {
-            fast = vec && (x0 + 128 <= X);
+            fast = vec && (x0 + W <= X);
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 const int x = x0 + tid / KL + XR * r;
@@ -55,11 +56,11 @@ struct TileLoader {
             }
             kstride = 1;
         } else {
-            fast = vec && (x0 + 128 <= X) && (rm.rpg >= rows_k);
+            fast = vec && (x0 + W <= X) && (rm.rpg >= rows_k);
             kstride = rm.ld;
 #pragma unroll
             for (int r = 0; r < NV; ++r)
-                base[r] = P + (long long)((tid >> 5) + 8 * r) * rm.ld + x0 + (tid & 31) * 4;
+                base[r] = P + (long long)(tid / XL + KR * r) * rm.ld + x0 + (tid % XL) * 4;
         }
     }
 
@@ -90,10 +91,10 @@ struct TileLoader {
                 v[r] = t;
             }
         } else {
-            const int x = x0 + (tid & 31) * 4;
+            const int x = x0 + (tid % XL) * 4;
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
-                const int k = kt0 + (tid >> 5) + 8 * r;
+                const int k = kt0 + tid / XL + KR * r;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend && x < X) {
                     const float* p = P + rm.off(k) + x;
@@ -123,47 +124,35 @@ struct TileLoader {
                 S[k4 + 3][x] = v[r].w;
             }
         } else {
-            const int x4 = (tid & 31) * 4;
+            const int x4 = (tid % XL) * 4;
 #pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const int k = (tid >> 5) + 8 * r;
-                *reinterpret_cast<float4*>(&S[k][x4]) = v[r];
-            }
+            for (int r = 0; r < NV; ++r)
+                *reinterpret_cast<float4*>(&S[tid / XL + KR * r][x4]) = v[r];
         }
     }
 };
 
-// One 128 x 128 output tile over k in [kbeg, kend).  Pipeline: global loads run TWO k-tiles ahead of
-// the MFMAs (registers), LDS is double buffered, one barrier per k-tile.
-template <bool AK, bool BK>
-__device__ inline void gemm_tile(const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
-                                 float* __restrict__ C, const RowMap& rc, const float* __restrict__ bias,
-                                 int M, int N, int K, int m0, int n0, int kbeg, int kend, int accumulate,
-                                 int vecA, int vecB, float* __restrict__ colsum_out,
-                                 float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
-    // colsum_out (or null): colsum_out[m - m0 ...] receives sum_k A(k, m) over this block's k range,
-    // folded from the LDS copy of the A tile (thread -> column tid & 127, k half tid >> 7)
+// acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Pipeline: global
+// loads run TWO k-tiles ahead of the MFMAs (registers), LDS is double buffered, one barrier per k-tile.
+// csum (TN form, optional): running column sums of the staged A tile (bias gradient).
+template <bool AK, bool BK, int MI>
+__device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
+                                       const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
+                                       int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
+                                       float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
+    constexpr int WM = 64 * MI;
+    using LA = TileLoader<AK, WM>;
+    using LB = TileLoader<BK, 128>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float csum = 0.f;
-
-    TileLoader<AK> la;
-    TileLoader<BK> lb;
+    LA la;
+    LB lb;
     la.init(A, ra, m0, M, K, tid, vecA);
     lb.init(B, rb, n0, N, K, tid, vecB);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
     const int li = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BKT - 1) / BKT;
 
-    float4 ra0[NV], rb0[NV], ra1[NV], rb1[NV];      // tiles kt+1 and kt+2 in flight
+    float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
         la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA);
         lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB);
@@ -178,41 +167,50 @@ __device__ inline void gemm_tile(const float* __restrict__ A, const RowMap& ra, 
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        // registers: (ra1, rb1) hold tile kt+1; request tile kt+2 into (ra0, rb0)
         if (kt + 2 < nkt) {
             la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA);
             lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB);
         }
 #pragma unroll
         for (int kk = 0; kk < BKT; kk += 2) {
-            float a[2], b[2];
+            float a[MI], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[buf][kk + lk][wm + i * 32 + li];
+            for (int i = 0; i < MI; ++i) a[i] = As[buf][kk + lk][wm + i * 32 + li];
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = Bs[buf][kk + lk][wn + j * 32 + li];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (colsum_out) {
-            const int cm = tid & 127, kh = (tid >> 7) * (BKT / 2);
+        if (csum) {
+            constexpr int G = 256 / WM, KG = BKT / G;          // k groups and rows per group
+            const int cm = tid % WM, kh = (tid / WM) * KG;
 #pragma unroll
-            for (int kk = 0; kk < BKT / 2; ++kk) csum += As[buf][kh + kk][cm];
+            for (int kk = 0; kk < KG; ++kk) *csum += As[buf][kh + kk][cm];
         }
         if (kt + 1 < nkt) {
             la.store(ra1, As[buf ^ 1], tid);
             lb.store(rb1, Bs[buf ^ 1], tid);
 #pragma unroll
-            for (int r = 0; r < NV; ++r) { ra1[r] = ra0[r]; rb1[r] = rb0[r]; }
+            for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
+#pragma unroll
+            for (int r = 0; r < LB::NV; ++r) rb1[r] = rb0[r];
         }
         __syncthreads();
     }
+}
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int MI>
+__device__ inline void gemm_store(const f32x16 (&acc)[MI][2], float* __restrict__ C, const RowMap& rc,
+                                  const float* __restrict__ bias, int M, int N, int m0, int n0, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
+    const int li = lane & 31, lk = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -230,26 +228,37 @@ __device__ inline void gemm_tile(const float* __restrict__ A, const RowMap& ra, 
             }
         }
     }
-    if (colsum_out) {
-        __syncthreads();
-        float* red = &Bs[0][0][0];
-        red[tid] = csum;
-        __syncthreads();
-        if (tid < 128 && m0 + tid < M) colsum_out[tid] = red[tid] + red[tid + 128];
-    }
 }
 
-template <bool AK, bool BK>
+template <int MI>
+__device__ inline void zero_acc(f32x16 (&acc)[MI][2]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// C (+)= A B (+ A2 B2) + bias.  MI = 1: 64 x 128 tiles (twice the blocks, for grids that would not fill
+// the chip with 128 x 128 tiles);  A2/B2: an optional second operand pair with the same row maps (the two
+// directions of a bidirectional layer summed in registers instead of a second accumulate pass).
+template <bool AK, bool BK, int MI>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
+    const float* __restrict__ A2, const float* __restrict__ B2, int K2,
     float* __restrict__ C, RowMap rc, const float* __restrict__ bias,
     int M, int N, int K, int kchunk, long long slab_stride, int accumulate, int vecA, int vecB) {
     __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
-    gemm_tile<AK, BK>(A, ra, B, rb, C + (long long)blockIdx.z * slab_stride, rc, bias, M, N, K,
-                      blockIdx.y * BM, blockIdx.x * BN, kbeg, kend, accumulate, vecA, vecB, nullptr, As, Bs);
+    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * BN;
+    f32x16 acc[MI][2];
+    zero_acc<MI>(acc);
+    gemm_accumulate<AK, BK, MI>(acc, nullptr, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
+    if (A2) gemm_accumulate<AK, BK, MI>(acc, nullptr, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
+    gemm_store<MI>(acc, C + (long long)blockIdx.z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
 // Grouped TN GEMM: up to TN_MAXP weight-gradient problems  C_p = A_p^T B_p  (+ column sums of A_p
@@ -291,8 +300,20 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     rs.gs = 0; rs.ld = P.N; rs.rpg = 1 << 30;
     float* slab = ws + P.slab_off + (long long)z * P.M * Nout;
     float* cs = (P.colsum && tn == 0) ? slab + (long long)P.M * P.N + tm * BM : nullptr;
-    gemm_tile<false, false>(P.A, P.ra, P.B, P.rb, slab, rs, nullptr, P.M, P.N, P.K, tm * BM, tn * BN, kbeg, kend, 0,
-                            P.vecA, P.vecB, cs, As, Bs);
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    float csum = 0.f;
+    gemm_accumulate<false, false, 2>(acc, cs ? &csum : nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
+                                     kbeg, kend, P.vecA, P.vecB, As, Bs);
+    gemm_store<2>(acc, slab, rs, nullptr, P.M, P.N, tm * BM, tn * BN, 0);
+    if (cs) {                                   // fold the two k-groups of the column sums through LDS
+        const int tid = threadIdx.x;
+        float* red = &Bs[0][0][0];
+        __syncthreads();
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 128 && tm * BM + tid < P.M) cs[tid] = red[tid] + red[tid + 128];
+    }
 }
 
 __global__ void gemm_tn_grouped_reduce(TnGroup g, const float* __restrict__ ws) {
@@ -348,6 +369,36 @@ int tn_splits(int M, int N, int K) {
 
 }  // namespace
 
+namespace {
+// 64-row tiles when 128-row tiles would leave the chip under-filled (< ~2 blocks per CU)
+inline bool use_small_tiles(int M, int N) {
+    static const int thr = [] {
+        const char* e = getenv("XPS_GEMM_SMALL_TILE_BLOCKS");
+        int v = e ? atoi(e) : -1;
+        return v >= 0 ? v : 1024;
+    }();
+    return M > 64 && (long long)cdiv(M, 128) * cdiv(N, BN) < thr;
+}
+
+template <bool AK, bool BK>
+int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& rb, const float* A2, const float* B2, int K2,
+                float* C, const RowMap& rc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st) {
+    const int kchunk = ((K + BKT - 1) / BKT) * BKT + BKT;
+    const int vecA = (int)(map_vec_ok(A, ra) && (!A2 || map_vec_ok(A2, ra)));
+    const int vecB = (int)(map_vec_ok(B, rb) && (!B2 || map_vec_ok(B2, rb)));
+    if (use_small_tiles(M, N)) {
+        dim3 grid(cdiv(N, BN), cdiv(M, 64), 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
+                           M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+    } else {
+        dim3 grid(cdiv(N, BN), cdiv(M, 128), 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
+                           M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+}  // namespace
+
 extern "C" int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra_, const float* B, const xps_rowmap* rb_,
                                float* C, const xps_rowmap* rc_, const float* bias,
                                int M, int N, int K, int accumulate, void* stream) {
@@ -355,11 +406,10 @@ extern "C" int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra_, const floa
     XPS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     if (M == 0 || N == 0) return XPS_OK;
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
-                       A, ra, B, rb, C, rc, bias, M, N, K, ((K + BKT - 1) / BKT) * BKT + BKT, 0LL, accumulate,
-                       (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
-    XPS_CHECK_LAUNCH();
+    if (launch_gemm<true, true>(A, ra, B, rb, nullptr, nullptr, 0, C, rc, bias, M, N, K, accumulate, (hipStream_t)stream)) {
+        xps_set_error("xps_gemm_nt_f32: launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return XPS_E_HIP;
+    }
     return XPS_OK;
 }
 
@@ -370,11 +420,24 @@ extern "C" int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra_, const floa
     XPS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     if (M == 0 || N == 0) return XPS_OK;
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream,
-                       A, ra, B, rb, C, rc, (const float*)nullptr, M, N, K, ((K + BKT - 1) / BKT) * BKT + BKT, 0LL,
-                       accumulate, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
-    XPS_CHECK_LAUNCH();
+    if (launch_gemm<true, false>(A, ra, B, rb, nullptr, nullptr, 0, C, rc, nullptr, M, N, K, accumulate, (hipStream_t)stream)) {
+        xps_set_error("xps_gemm_nn_f32: launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return XPS_E_HIP;
+    }
+    return XPS_OK;
+}
+
+extern "C" int xps_gemm_nn2_f32(const float* A1, const float* B1, int K1, const float* A2, const float* B2, int K2,
+                                const xps_rowmap* ra_, const xps_rowmap* rb_, float* C, const xps_rowmap* rc_,
+                                int M, int N, int accumulate, void* stream) {
+    XPS_CHECK_ARG(A1 && B1 && A2 && B2 && C && ra_ && rb_ && rc_, "null argument");
+    XPS_CHECK_ARG(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
+    if (M == 0 || N == 0) return XPS_OK;
+    RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
+    if (launch_gemm<true, false>(A1, ra, B1, rb, A2, B2, K2, C, rc, nullptr, M, N, K1, accumulate, (hipStream_t)stream)) {
+        xps_set_error("xps_gemm_nn2_f32: launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return XPS_E_HIP;
+    }
     return XPS_OK;
 }
 
@@ -405,9 +468,9 @@ extern "C" int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra_, const floa
     rs.gs = 0; rs.ld = N; rs.rpg = 1 << 30;
     const long long slab_stride = (long long)M * N;
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream,
-                       A, ra, B, rb, slabs, rs, (const float*)nullptr, M, N, K, kchunk, slab_stride, 0,
-                       (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, (hipStream_t)stream,
+                       A, ra, B, rb, (const float*)nullptr, (const float*)nullptr, 0, slabs, rs, (const float*)nullptr,
+                       M, N, K, kchunk, slab_stride, 0, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
     XPS_CHECK_LAUNCH();
     long long total = (long long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,

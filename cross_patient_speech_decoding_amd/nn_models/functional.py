@@ -306,8 +306,12 @@ class GRULayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, In, dtype=_f32, device=dev)
-            for d in range(ndir):
-                gemm_nn(dgi[d], w_ih[d], dx, T * B, In, 3 * H, accumulate=(d > 0))
+            if ndir == 2:       # both directions summed in registers: one launch, no accumulate pass over dx
+                ra, rb, rc = rowmap(3 * H), rowmap(In), rowmap(In)
+                call('xps_gemm_nn2_f32', _ptr(dgi[0]), _ptr(w_ih[0]), 3 * H, _ptr(dgi[1]), _ptr(w_ih[1]), 3 * H,
+                     C.byref(ra), C.byref(rb), _ptr(dx), C.byref(rc), T * B, In, 0, _stream())
+            else:
+                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H)
         probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_ext, [wb[4 * d + 1] for d in range(ndir)],
                                                   [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir)
         rets_ih = []

@@ -64,6 +64,11 @@ int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra, const float* B, const 
 int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra, const float* B, const xps_rowmap* rb,
                     float* C, const xps_rowmap* rc,
                     int M, int N, int K, int accumulate, void* stream);
+/* C (+)= A1 B1 + A2 B2  (A_i: M x K_i, B_i: K_i x N, both pairs share the row maps): the input gradient of
+ * a bidirectional layer, both directions summed in registers in one launch.    */
+int xps_gemm_nn2_f32(const float* A1, const float* B1, int K1, const float* A2, const float* B2, int K2,
+                     const xps_rowmap* ra, const xps_rowmap* rb, float* C, const xps_rowmap* rc,
+                     int M, int N, int accumulate, void* stream);
 /* C[m][n] (+)= sum_k A[k][m] * B[k][n]                (A: K x M, B: K x N)
  * split-K over deterministic partial slabs in `workspace`.                    */
 size_t xps_gemm_tn_f32_workspace(int M, int N, int K);
