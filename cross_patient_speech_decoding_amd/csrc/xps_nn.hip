@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int RED_ROWS = 256;   // rows folded by one block of the first reduction stage
+constexpr int RED_ROWS = 64;    // rows folded by one block of the first reduction stage (16 per thread)
 
 // stage 1: block (bx, by) sums rows [by*RED_ROWS, ...) of columns [bx*64, bx*64+64)
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, long long ldx, int rows, int cols,
@@ -17,12 +17,14 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X
     const int r0 = blockIdx.y * RED_ROWS;
     const int r1 = min(rows, r0 + RED_ROWS);
     float a = 0.f, a2 = 0.f;
-    if (c < cols)
+    if (c < cols) {
+#pragma unroll 4
         for (int r = r0 + rq; r < r1; r += 4) {
             float v = X[(long long)r * ldx + c];
             a += v;
             a2 += v * v;
         }
+    }
     s1[rq][threadIdx.x & 63] = a;
     s2[rq][threadIdx.x & 63] = a2;
     __syncthreads();
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const float* __restrict__ d
     float a = 0.f, a2 = 0.f;
     if (c < F) {
         const float m = mean[c], rs = rstd[c];
+#pragma unroll 4
         for (long long r = r0 + rq; r < r1; r += 4) {
             const long long i = r * F + c;
             float g = dout[i];
@@ -163,7 +166,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const long l
 // stage 1: block (strip of 64 columns, chunk of 64 batch rows) accumulates into an LDS copy of the
 //          table (each thread owns one (row-group, column): no atomics) and writes its partial table;
 // stage 2: partial tables are summed in chunk order.
-constexpr int SC_CHUNK = 64, SC_MAXROWS = 16;
+constexpr int SC_CHUNK = 256, SC_MAXROWS = 16;
 __global__ __launch_bounds__(256) void scatter_rows_stage1(const float* __restrict__ dout, const long long* __restrict__ idx,
                                                            float* __restrict__ part, int B, int cols, int n_rows) {
     __shared__ float tab[4][SC_MAXROWS][64];
@@ -291,7 +294,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
     for (int c = 0; c < C; ++c) dlogits[r * C + c] = g * (expf(p[c] - mx) * inv - (c == tg ? 1.f : 0.f));
 }
 
-constexpr int SS_CHUNK = 8192;
+constexpr int SS_CHUNK = 2048;
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, long long n, double* __restrict__ part) {
     __shared__ double sh[256];
     const long long i0 = (long long)blockIdx.x * SS_CHUNK;
