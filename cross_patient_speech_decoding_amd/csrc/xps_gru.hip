@@ -46,6 +46,8 @@ __device__ inline float4 load_w4(const float* __restrict__ row, int k, int H) {
     return t;
 }
 
+__device__ inline float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -102,30 +104,51 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdParams p) {
             const float* wn = W + (long long)(2 * H + jc) * H;
             f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
 
-            float4 br = load_w4<VEC>(wr, 4 * kq, H);
-            float4 bz = load_w4<VEC>(wz, 4 * kq, H);
-            float4 bn = load_w4<VEC>(wn, 4 * kq, H);
-            for (int k0 = 0; k0 < Hp; k0 += 16) {
-                const int kk = k0 + 4 * kq;
-                const float4 a = *reinterpret_cast<const float4*>(hc + n * ldh + kk);
-                const float4 cr = br, cz = bz, cn = bn;
-                if (k0 + 16 < Hp) {
-                    br = load_w4<VEC>(wr, kk + 16, H);
-                    bz = load_w4<VEC>(wz, kk + 16, H);
-                    bn = load_w4<VEC>(wn, kk + 16, H);
+            // W_hh streams from L2: keep TWO groups of PF k-chunks (3 gates x PF x 16 B per lane) in flight so
+            // that the memory-level parallelism, not the L2 latency, sets the rate
+            constexpr int PF = 4;
+            float4 wb[2][PF][3];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int kk = 16 * u + 4 * kq;
+                wb[0][u][0] = load_w4<VEC>(wr, kk, H);
+                wb[0][u][1] = load_w4<VEC>(wz, kk, H);
+                wb[0][u][2] = load_w4<VEC>(wn, kk, H);
+            }
+            for (int k0 = 0; k0 < Hp; k0 += 32 * PF) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int kb = k0 + half * 16 * PF;            // first k of the group being multiplied
+                    if (kb < Hp) {
+#pragma unroll
+                        for (int u = 0; u < PF; ++u) {             // request the following group
+                            const int kk = kb + 16 * PF + 16 * u + 4 * kq;
+                            wb[half ^ 1][u][0] = load_w4<VEC>(wr, kk, H);
+                            wb[half ^ 1][u][1] = load_w4<VEC>(wz, kk, H);
+                            wb[half ^ 1][u][2] = load_w4<VEC>(wn, kk, H);
+                        }
+#pragma unroll
+                        for (int u = 0; u < PF; ++u) {
+                            const int kc = kb + 16 * u;
+                            if (kc < Hp) {
+                                const float4 a = *reinterpret_cast<const float4*>(hc + n * ldh + kc + 4 * kq);
+                                const float4 cr = wb[half][u][0], cz = wb[half][u][1], cn = wb[half][u][2];
+                                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cr.x, acc_r, 0, 0, 0);
+                                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cz.x, acc_z, 0, 0, 0);
+                                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cn.x, acc_n, 0, 0, 0);
+                                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cr.y, acc_r, 0, 0, 0);
+                                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cz.y, acc_z, 0, 0, 0);
+                                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cn.y, acc_n, 0, 0, 0);
+                                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cr.z, acc_r, 0, 0, 0);
+                                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cz.z, acc_z, 0, 0, 0);
+                                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cn.z, acc_n, 0, 0, 0);
+                                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cr.w, acc_r, 0, 0, 0);
+                                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cz.w, acc_z, 0, 0, 0);
+                                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cn.w, acc_n, 0, 0, 0);
+                            }
+                        }
+                    }
                 }
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cr.x, acc_r, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cz.x, acc_z, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, cn.x, acc_n, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cr.y, acc_r, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cz.y, acc_z, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, cn.y, acc_n, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cr.z, acc_r, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cz.z, acc_z, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, cn.z, acc_n, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cr.w, acc_r, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cz.w, acc_z, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, cn.w, acc_n, 0, 0, 0);
             }
 
             // gates + hidden update; D layout: row = 4*kq + i, col = n
@@ -198,6 +221,53 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
     for (int s = T - 1; s >= 0; --s) {
         const int t = (dir == 0) ? s : T - 1 - s;
         const int slot_prev = (dir == 0) ? t : t + 2;
+        if (VEC) {
+            // 4 consecutive hidden units per thread, 16-byte accesses (H % 4 == 0 on this path; Hp - H < 16 pad
+            // columns are written as zeros)
+            const int Hq = Hp / 4;
+            for (int idx = tid; idx < GBM * Hq; idx += 256) {
+                const int r = idx / Hq, j = (idx % Hq) * 4, b = b0 + r;
+                float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, danr = dar, keep = dar;
+                if (b < B && j < H) {
+                    const float4 dy4 = p.dy ? *reinterpret_cast<const float4*>(p.dy + ((long long)t * B + b) * ldy + dir * H + j)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 cy4 = *reinterpret_cast<const float4*>(&Cy[r * ldc + j]);
+                    const float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H;
+                    const float4 rg = *reinterpret_cast<const float4*>(sv + j);
+                    const float4 zg = *reinterpret_cast<const float4*>(sv + H + j);
+                    const float4 ng = *reinterpret_cast<const float4*>(sv + 2 * H + j);
+                    const float4 q = *reinterpret_cast<const float4*>(sv + 3 * H + j);
+                    const float4 hp = *reinterpret_cast<const float4*>(p.y_ext + ((long long)slot_prev * B + b) * ldy + dir * H + j);
+                    float o_dar[4], o_daz[4], o_dan[4], o_danr[4], o_keep[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float dh = f4get(dy4, i) + f4get(cy4, i);
+                        const float r_ = f4get(rg, i), z_ = f4get(zg, i), n_ = f4get(ng, i);
+                        const float dn = dh * (1.f - z_);
+                        const float dz = dh * (f4get(hp, i) - n_);
+                        const float dan = dn * (1.f - n_ * n_);
+                        o_daz[i] = dz * z_ * (1.f - z_);
+                        o_dar[i] = dan * f4get(q, i) * r_ * (1.f - r_);
+                        o_dan[i] = dan;
+                        o_danr[i] = dan * r_;
+                        o_keep[i] = dh * z_;
+                    }
+                    dar = make_float4(o_dar[0], o_dar[1], o_dar[2], o_dar[3]);
+                    daz = make_float4(o_daz[0], o_daz[1], o_daz[2], o_daz[3]);
+                    danr = make_float4(o_danr[0], o_danr[1], o_danr[2], o_danr[3]);
+                    keep = make_float4(o_keep[0], o_keep[1], o_keep[2], o_keep[3]);
+                    const long long o = (((long long)dir * T + t) * B + b) * 3 * H;
+                    *reinterpret_cast<float4*>(p.dgi + o + j) = dar;
+                    *reinterpret_cast<float4*>(p.dgi + o + H + j) = daz;
+                    *reinterpret_cast<float4*>(p.dgi + o + 2 * H + j) = make_float4(o_dan[0], o_dan[1], o_dan[2], o_dan[3]);
+                    *reinterpret_cast<float4*>(p.dghn + (((long long)dir * T + t) * B + b) * H + j) = danr;
+                }
+                *reinterpret_cast<float4*>(&G[r * ldg + j]) = dar;
+                *reinterpret_cast<float4*>(&G[r * ldg + Hp + j]) = daz;
+                *reinterpret_cast<float4*>(&G[r * ldg + 2 * Hp + j]) = danr;
+                *reinterpret_cast<float4*>(&Cy[r * ldc + j]) = keep;
+            }
+        } else
         for (int idx = tid; idx < GBM * Hp; idx += 256) {
             const int r = idx / Hp, j = idx % Hp, b = b0 + r;
             float dar = 0.f, daz = 0.f, danr = 0.f, keep = 0.f;
@@ -229,7 +299,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
         for (int jt = wave; jt < ntile; jt += 4) {
             const int j = jt * 16 + n;
             const int jc = j < H ? j : H - 1;
-            f32x4 acc;
+            f32x4 acc, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = Cy[(4 * kq + i) * ldc + j];
             const float* wrow = WT + (long long)jc * 3 * H;
@@ -237,22 +307,39 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
             for (int g = 0; g < 3; ++g) {
                 const float* wg = wrow + g * H;
                 const float* ag = G + n * ldg + g * Hp;
-                float4 bw = load_w4<VEC>(wg, 4 * kq, H);
-                for (int k0 = 0; k0 < Hp; k0 += 16) {
-                    const int kk = k0 + 4 * kq;
-                    const float4 a = *reinterpret_cast<const float4*>(ag + kk);
-                    const float4 c = bw;
-                    if (k0 + 16 < Hp) bw = load_w4<VEC>(wg, kk + 16, H);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, c.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, c.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, c.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, c.w, acc, 0, 0, 0);
+                constexpr int PF = 8;                       // k-chunks per prefetch group (one gate segment at a time)
+                float4 wb[2][PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) wb[0][u] = load_w4<VEC>(wg, 16 * u + 4 * kq, H);
+                for (int k0 = 0; k0 < Hp; k0 += 32 * PF) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int kb = k0 + half * 16 * PF;
+                        if (kb < Hp) {
+#pragma unroll
+                            for (int u = 0; u < PF; ++u)
+                                wb[half ^ 1][u] = load_w4<VEC>(wg, kb + 16 * PF + 16 * u + 4 * kq, H);
+#pragma unroll
+                            for (int u = 0; u < PF; ++u) {
+                                const int kc = kb + 16 * u;
+                                if (kc < Hp) {
+                                    const float4 a = *reinterpret_cast<const float4*>(ag + kc + 4 * kq);
+                                    const float4 c = wb[half][u];
+                                    // two accumulator chains (16x16x4: 32-cycle issue, 40-cycle dependent latency)
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, c.x, acc, 0, 0, 0);
+                                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, c.y, acc2, 0, 0, 0);
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, c.z, acc, 0, 0, 0);
+                                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, c.w, acc2, 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * kq + i;
-                Cy[r * ldc + j] = (b0 + r < B && j < H) ? acc[i] : 0.f;
+                Cy[r * ldc + j] = (b0 + r < B && j < H) ? acc[i] + acc2[i] : 0.f;
             }
         }
         __syncthreads();
@@ -282,7 +369,6 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdParams p) {
 // ---------------------------------------------------------------------------------------------
 __device__ inline float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ inline float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
-__device__ inline float f4get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 #ifdef XPS_STAMP
 // Diagnostic build only (never shipped): per-wave cycle shares of the step loop, written to a
