@@ -126,3 +126,13 @@ def test_data_parallel_two_ranks_equal_single_process():
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert 'DP_OK' in out.stdout
+
+
+def test_train_seq2seq_cli_end_to_end(tmp_path):
+    """The counterpart of scripts/train_seq2seq.py: pooled + CCA-aligned k-fold training on synthetic patients."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train_seq2seq.py'), '-pt', 'SYN', '-p', 'True',
+                          '--synthetic', '3', '--iters', '1', '--folds', '2', '--epochs', '15', '--hidden', '64',
+                          '--out', str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    accs = np.load(os.path.join(str(tmp_path), 'accs', 'SYN', 'SYN_pooled_accs.npy'))
+    assert accs.shape == (1, 2) and accs.mean() > 0.15            # chance 1/9
