@@ -40,6 +40,7 @@ SIGNATURES = {
     'xps_abi_version': (_i, []),
     'xps_gemm_nt_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),
     'xps_gemm_nn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp]),
+    'xps_gemm_nt_multi_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),
     'xps_gemm_nn2_f32': (_i, [_vp, _vp, _i, _vp, _vp, _i, _rm, _rm, _vp, _rm, _i, _i, _i, _vp]),
     'xps_gemm_tn_f32_workspace': (_sz, [_i, _i, _i]),
     'xps_gemm_tn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -27,6 +27,17 @@ namespace {
 #endif
 constexpr int BM = 128, BN = 128, BKT = XPS_BKT, LDT = 132;
 
+#ifdef XPS_GSTAMP
+// diagnostic build only: per-wave cycle shares of the k loop (written to a buffer no kernel reads)
+__device__ unsigned long long g_gstamp[8192 * 4];
+#define GSTAMP(var)                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);
+#else
+#define GSTAMP(var)
+#endif
+
 constexpr int KL = BKT / 4;          // KCONTIG: lanes covering one row's k range
 
 // Stages a (BKT x W) k-major tile of a matrix stored either [x][k] (KCONTIG) or [k][x]; W = 64 or 128.
@@ -165,12 +176,17 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
     }
     __syncthreads();
 
+#ifdef XPS_GSTAMP
+    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, s_ld = 0, s_mm = 0, s_st = 0, s_bar = 0;
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+        GSTAMP(g0)
         if (kt + 2 < nkt) {
             la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA);
             lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB);
         }
+        GSTAMP(g1)
 #pragma unroll
         for (int kk = 0; kk < BKT; kk += 2) {
             float a[MI], b[2];
@@ -190,6 +206,7 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
 #pragma unroll
             for (int kk = 0; kk < KG; ++kk) *csum += As[buf][kh + kk][cm];
         }
+        GSTAMP(g2)
         if (kt + 1 < nkt) {
             la.store(ra1, As[buf ^ 1], tid);
             lb.store(rb1, Bs[buf ^ 1], tid);
@@ -198,8 +215,19 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
 #pragma unroll
             for (int r = 0; r < LB::NV; ++r) rb1[r] = rb0[r];
         }
+        GSTAMP(g3)
         __syncthreads();
+#ifdef XPS_GSTAMP
+        GSTAMP(g4)
+        s_ld += g1 - g0; s_mm += g2 - g1; s_st += g3 - g2; s_bar += g4 - g3;
+#endif
     }
+#ifdef XPS_GSTAMP
+    if (lane == 0) {
+        const int wid = (((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave)) & 8191;
+        g_gstamp[wid * 4 + 0] = s_ld; g_gstamp[wid * 4 + 1] = s_mm; g_gstamp[wid * 4 + 2] = s_st; g_gstamp[wid * 4 + 3] = s_bar;
+    }
+#endif
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -259,6 +287,26 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     gemm_accumulate<AK, BK, MI>(acc, nullptr, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
     if (A2) gemm_accumulate<AK, BK, MI>(acc, nullptr, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
     gemm_store<MI>(acc, C + (long long)blockIdx.z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
+}
+
+// Same A, up to 4 different (B, bias, C): the input projections of all directions of a layer in ONE launch
+// (blockIdx.z selects the problem) — twice the blocks per launch halves the under-filled tail round.
+struct NtMulti {
+    const float* B[4];
+    const float* bias[4];
+    float* C[4];
+};
+template <int MI>
+__global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
+    const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    const int z = blockIdx.z;
+    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * BN;
+    f32x16 acc[MI][2];
+    zero_acc<MI>(acc);
+    gemm_accumulate<true, true, MI>(acc, nullptr, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, As, Bs);
+    gemm_store<MI>(acc, pm.C[z], rc, pm.bias[z], M, N, m0, n0, 0);
 }
 
 // Grouped TN GEMM: up to TN_MAXP weight-gradient problems  C_p = A_p^T B_p  (+ column sums of A_p
@@ -427,6 +475,34 @@ extern "C" int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra_, const floa
     return XPS_OK;
 }
 
+extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, const float* const* B, const xps_rowmap* rb_,
+                                     float* const* C, const xps_rowmap* rc_, const float* const* bias, int nprob,
+                                     int M, int N, int K, void* stream) {
+    XPS_CHECK_ARG(A && B && C && ra_ && rb_ && rc_, "null argument");
+    XPS_CHECK_ARG(nprob >= 1 && nprob <= 4, "1..4 problems");
+    XPS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
+    if (M == 0 || N == 0) return XPS_OK;
+    RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
+    NtMulti pm;
+    bool vb = true;
+    for (int i = 0; i < 4; ++i) {
+        const int j = i < nprob ? i : 0;
+        XPS_CHECK_ARG(B[j] && C[j], "null problem pointer");
+        pm.B[i] = B[j]; pm.C[i] = C[j]; pm.bias[i] = bias ? bias[j] : nullptr;
+        vb = vb && map_vec_ok(B[j], rb);
+    }
+    const int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
+    if (use_small_tiles(M, N * nprob)) {
+        hipLaunchKernelGGL((gemm_nt_multi_kernel<1>), dim3(cdiv(N, BN), cdiv(M, 64), nprob), dim3(256), 0, (hipStream_t)stream,
+                           A, ra, pm, rb, rc, M, N, K, vecA, vecB);
+    } else {
+        hipLaunchKernelGGL((gemm_nt_multi_kernel<2>), dim3(cdiv(N, BN), cdiv(M, 128), nprob), dim3(256), 0, (hipStream_t)stream,
+                           A, ra, pm, rb, rc, M, N, K, vecA, vecB);
+    }
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
 extern "C" int xps_gemm_nn2_f32(const float* A1, const float* B1, int K1, const float* A2, const float* B2, int K2,
                                 const xps_rowmap* ra_, const xps_rowmap* rb_, float* C, const xps_rowmap* rc_,
                                 int M, int N, int accumulate, void* stream) {
@@ -553,3 +629,9 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
+
+#ifdef XPS_GSTAMP
+extern "C" int xps_debug_read_gstamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gstamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -280,8 +280,9 @@ class GRULayerFn(torch.autograd.Function):
         b_hh = [wb[4 * d + 3].contiguous() for d in range(ndir)]
         H = w_hh[0].shape[1]
         gi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=x.device)
-        for d in range(ndir):
-            gemm_nt(x, w_ih[d], gi[d], T * B, 3 * H, In, bias=b_ih[d])
+        ra, rb, rc = rowmap(In), rowmap(In), rowmap(3 * H)          # all directions in ONE launch
+        call('xps_gemm_nt_multi_f32', _ptr(x), C.byref(ra), _ptr_array(w_ih), C.byref(rb), _ptr_array([gi[d] for d in range(ndir)]),
+             C.byref(rc), _ptr_array(b_ih), ndir, T * B, 3 * H, In, _stream())
         save = any(ctx.needs_input_grad)
         y_ext, saved = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
         if save:

@@ -64,6 +64,11 @@ int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra, const float* B, const 
 int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra, const float* B, const xps_rowmap* rb,
                     float* C, const xps_rowmap* rc,
                     int M, int N, int K, int accumulate, void* stream);
+/* nprob (1..4) problems C_i = A B_i^T + bias_i sharing A and all sizes / row maps, in ONE launch (the input
+ * projections of every direction of a GRU layer).  B, C, bias are HOST arrays of device pointers.       */
+int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra, const float* const* B, const xps_rowmap* rb,
+                          float* const* C, const xps_rowmap* rc, const float* const* bias, int nprob,
+                          int M, int N, int K, void* stream);
 /* C (+)= A1 B1 + A2 B2  (A_i: M x K_i, B_i: K_i x N, both pairs share the row maps): the input gradient of
  * a bidirectional layer, both directions summed in registers in one launch.    */
 int xps_gemm_nn2_f32(const float* A1, const float* B1, int K1, const float* A2, const float* B2, int K2,
