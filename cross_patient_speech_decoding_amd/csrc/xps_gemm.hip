@@ -16,257 +16,9 @@
 // time-major outputs.
 #include <stdlib.h>
 #include "xps_common.h"
-
+#include "xps_gemm_tile.h"
+using namespace xps_tile;
 namespace {
-
-#ifndef XPS_BKT
-#define XPS_BKT 16
-#endif
-#ifndef XPS_GEMM_WAVES
-#define XPS_GEMM_WAVES 1
-#endif
-constexpr int BM = 128, BN = 128, BKT = XPS_BKT, LDT = 132;
-
-#ifdef XPS_GSTAMP
-// diagnostic build only: per-wave cycle shares of the k loop (written to a buffer no kernel reads)
-__device__ unsigned long long g_gstamp[8192 * 4];
-#define GSTAMP(var)                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");      \
-    __builtin_amdgcn_sched_barrier(0);
-#else
-#define GSTAMP(var)
-#endif
-
-constexpr int KL = BKT / 4;          // KCONTIG: lanes covering one row's k range
-
-// Stages a (BKT x W) k-major tile of a matrix stored either [x][k] (KCONTIG) or [k][x]; W = 64 or 128.
-template <bool KCONTIG, int W>
-struct TileLoader {
-    // KCONTIG : 16-byte vectors along k; thread -> (x = tid / KL (+ XR per pass), k4 = (tid % KL) * 4)
-    // !KCONTIG: 16-byte vectors along x; thread -> (k = tid / XL (+ KR per pass), x4 = (tid % XL) * 4)
-    // `fast` (block-uniform): the W-wide x range is fully inside the matrix, vectors are aligned and
-    // the row map is a plain leading dimension -> no per-element guards, no divisions in the k loop.
-    static constexpr int XR = 256 / KL;                 // KCONTIG: x rows per pass
-    static constexpr int XL = W / 4;                    // !KCONTIG: lanes per k row
-    static constexpr int KR = 256 / XL;                 // !KCONTIG: k rows per pass
-    static constexpr int NV = KCONTIG ? W / XR : BKT / KR;
-    const float* base[NV];
-    long long xoff[NV];
-    long long kstride;
-    bool fast;
-
-    __device__ inline void init(const float* __restrict__ P, const RowMap& rm, int x0, int X, int rows_k, int tid, bool vec) {
-        if (KCONTIG) {
-            fast = vec && (x0 + W <= X);
-#pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const int x = x0 + tid / KL + XR * r;
-                xoff[r] = (x < X) ? rm.off(x) : -1;
-                base[r] = P + (xoff[r] >= 0 ? xoff[r] : 0) + (tid % KL) * 4;
-            }
-            kstride = 1;
-        } else {
-            fast = vec && (x0 + W <= X) && (rm.rpg >= rows_k);
-            kstride = rm.ld;
-#pragma unroll
-            for (int r = 0; r < NV; ++r)
-                base[r] = P + (long long)(tid / XL + KR * r) * rm.ld + x0 + (tid % XL) * 4;
-        }
-    }
-
-    __device__ inline void load(float4 (&v)[NV], const float* __restrict__ P, const RowMap& rm, int x0, int X,
-                                int kt0, int kend, int tid, bool vec) const {
-        if (fast && kt0 + BKT <= kend) {
-#pragma unroll
-            for (int r = 0; r < NV; ++r)
-                v[r] = *reinterpret_cast<const float4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
-            return;
-        }
-        if (KCONTIG) {
-            const int k = kt0 + (tid % KL) * 4;
-#pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (xoff[r] >= 0) {
-                    const float* p = P + xoff[r] + k;
-                    if (vec && k + 3 < kend) {
-                        t = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (k + 0 < kend) t.x = p[0];
-                        if (k + 1 < kend) t.y = p[1];
-                        if (k + 2 < kend) t.z = p[2];
-                        if (k + 3 < kend) t.w = p[3];
-                    }
-                }
-                v[r] = t;
-            }
-        } else {
-            const int x = x0 + (tid % XL) * 4;
-#pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const int k = kt0 + tid / XL + KR * r;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < kend && x < X) {
-                    const float* p = P + rm.off(k) + x;
-                    if (vec && x + 3 < X) {
-                        t = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        t.x = p[0];
-                        if (x + 1 < X) t.y = p[1];
-                        if (x + 2 < X) t.z = p[2];
-                        if (x + 3 < X) t.w = p[3];
-                    }
-                }
-                v[r] = t;
-            }
-        }
-    }
-
-    __device__ inline void store(const float4 (&v)[NV], float (*S)[LDT], int tid) const {
-        if (KCONTIG) {
-            const int k4 = (tid % KL) * 4;
-#pragma unroll
-            for (int r = 0; r < NV; ++r) {
-                const int x = tid / KL + XR * r;
-                S[k4 + 0][x] = v[r].x;
-                S[k4 + 1][x] = v[r].y;
-                S[k4 + 2][x] = v[r].z;
-                S[k4 + 3][x] = v[r].w;
-            }
-        } else {
-            const int x4 = (tid % XL) * 4;
-#pragma unroll
-            for (int r = 0; r < NV; ++r)
-                *reinterpret_cast<float4*>(&S[tid / XL + KR * r][x4]) = v[r];
-        }
-    }
-};
-
-// acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Pipeline: global
-// loads run TWO k-tiles ahead of the MFMAs (registers), LDS is double buffered, one barrier per k-tile.
-// csum (TN form, optional): running column sums of the staged A tile (bias gradient).
-template <bool AK, bool BK, int MI>
-__device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
-                                       const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
-                                       int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
-                                       float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
-    constexpr int WM = 64 * MI;
-    using LA = TileLoader<AK, WM>;
-    using LB = TileLoader<BK, 128>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    LA la;
-    LB lb;
-    la.init(A, ra, m0, M, K, tid, vecA);
-    lb.init(B, rb, n0, N, K, tid, vecB);
-    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
-    const int li = lane & 31, lk = lane >> 5;
-    const int nkt = (kend - kbeg + BKT - 1) / BKT;
-
-    float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
-    if (nkt > 0) {
-        la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA);
-        lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB);
-        if (nkt > 1) {
-            la.load(ra1, A, ra, m0, M, kbeg + BKT, kend, tid, vecA);
-            lb.load(rb1, B, rb, n0, N, kbeg + BKT, kend, tid, vecB);
-        }
-        la.store(ra0, As[0], tid);
-        lb.store(rb0, Bs[0], tid);
-    }
-    __syncthreads();
-
-#ifdef XPS_GSTAMP
-    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, s_ld = 0, s_mm = 0, s_st = 0, s_bar = 0;
-#endif
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        GSTAMP(g0)
-        if (kt + 2 < nkt) {
-            la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA);
-            lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB);
-        }
-        GSTAMP(g1)
-#pragma unroll
-        for (int kk = 0; kk < BKT; kk += 2) {
-            float a[MI], b[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = As[buf][kk + lk][wm + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[buf][kk + lk][wn + j * 32 + li];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (csum) {
-            constexpr int G = 256 / WM, KG = BKT / G;          // k groups and rows per group
-            const int cm = tid % WM, kh = (tid / WM) * KG;
-#pragma unroll
-            for (int kk = 0; kk < KG; ++kk) *csum += As[buf][kh + kk][cm];
-        }
-        GSTAMP(g2)
-        if (kt + 1 < nkt) {
-            la.store(ra1, As[buf ^ 1], tid);
-            lb.store(rb1, Bs[buf ^ 1], tid);
-#pragma unroll
-            for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
-#pragma unroll
-            for (int r = 0; r < LB::NV; ++r) rb1[r] = rb0[r];
-        }
-        GSTAMP(g3)
-        __syncthreads();
-#ifdef XPS_GSTAMP
-        GSTAMP(g4)
-        s_ld += g1 - g0; s_mm += g2 - g1; s_st += g3 - g2; s_bar += g4 - g3;
-#endif
-    }
-#ifdef XPS_GSTAMP
-    if (lane == 0) {
-        const int wid = (((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave)) & 8191;
-        g_gstamp[wid * 4 + 0] = s_ld; g_gstamp[wid * 4 + 1] = s_mm; g_gstamp[wid * 4 + 2] = s_st; g_gstamp[wid * 4 + 3] = s_bar;
-    }
-#endif
-}
-
-// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int MI>
-__device__ inline void gemm_store(const f32x16 (&acc)[MI][2], float* __restrict__ C, const RowMap& rc,
-                                  const float* __restrict__ bias, int M, int N, int m0, int n0, int accumulate) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
-    const int li = lane & 31, lk = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row >= M) continue;
-            float* crow = C + rc.off(row);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn + j * 32 + li;
-                if (col < N) {
-                    float v = acc[i][j][r];
-                    if (bias) v += bias[col];
-                    if (accumulate) v += crow[col];
-                    crow[col] = v;
-                }
-            }
-        }
-    }
-}
-
-template <int MI>
-__device__ inline void zero_acc(f32x16 (&acc)[MI][2]) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-}
 
 // C (+)= A B (+ A2 B2) + bias.  MI = 1: 64 x 128 tiles (twice the blocks, for grids that would not fill
 // the chip with 128 x 128 tiles);  A2/B2: an optional second operand pair with the same row maps (the two

@@ -17,7 +17,9 @@
 // PyTorch GRU semantics (gate order r, z, n):
 //   r = s(gi_r + W_hr h + b_hr)   z = s(gi_z + W_hz h + b_hz)
 //   n = tanh(gi_n + r * (W_hn h + b_hn))     h' = n + z * (h - n)
+#include <stdlib.h>
 #include "xps_common.h"
+#include "xps_gemm_tile.h"
 
 namespace {
 
@@ -714,6 +716,214 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large hidden sizes (H > 128: W_hh no longer fits one CU's registers).  One launch PER TIME STEP;
+// the kernel boundary is the inter-workgroup exchange of h_t, so no in-kernel grid synchronisation
+// is needed.  Each workgroup computes, for 128 trials x 32 hidden units, the three gate
+// pre-activations h_{t-1} W_hh^T on the 32x32x2 fp32 MFMA (tile machinery of xps_gemm_tile.h:
+// k-major LDS staging, loads two k-tiles ahead) and applies the gate math in the epilogue: the
+// r, z, n accumulators of a (trial, unit) pair live in the same lane.  B-operand rows are the
+// gate-strided rows {g*H + j} of W_hh, addressed by a two-level row map.  Grid = (H/32, B/128, ndir).
+// ---------------------------------------------------------------------------------------------
+struct GruStepFwd {
+    const float* gi;        // (ndir, T, B, 3H)
+    const float* w_hh[2];
+    const float* b_hh[2];
+    float* y_ext;           // (T+2, B, ndir*H)
+    float* saved;           // (ndir, T, B, 4H) or null
+    int T, B, H, ndir, s;   // s = processing step
+    int vecA, vecB;
+};
+
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
+    using namespace xps_tile;
+    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    const int dir = blockIdx.z, H = p.H, B = p.B, T = p.T;
+    const int t = (dir == 0) ? p.s : T - 1 - p.s;
+    const int slot_prev = (dir == 0) ? t : t + 2;
+    const int ldy = p.ndir * H;
+    const int j0 = blockIdx.x * 32, m0 = blockIdx.y * 128;
+    const float* hprev = p.y_ext + (long long)slot_prev * B * ldy + dir * H;     // (B x H), ld = ldy
+    RowMap ra; ra.gs = 0; ra.ld = ldy; ra.rpg = 1 << 30;
+    RowMap rb; rb.gs = (long long)H * H; rb.ld = H; rb.rpg = 32;                  // row x -> (x/32)*H*H + (x%32)*H
+    const float* Wb = p.w_hh[dir] + (long long)j0 * H;
+    // units beyond H in the last tile: clamp the loader's row range per gate by shrinking X to the valid rows
+    const int nu = min(32, H - j0);
+    f32x16 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    {
+        // gemm_accumulate works on a (MI x 2) grid of 32x32 tiles per wave (64 x 64); here a wave owns
+        // 32 trials x (3 gates x 32 units), so the k pipeline is restated for that shape.
+        using LA = TileLoader<true, 128>;
+        using LB = TileLoader<true, 128>;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        LA la; LB lb;
+        la.init(hprev, ra, m0, B, H, tid, p.vecA);
+        lb.init(Wb, rb, 0, (nu == 32) ? 96 : 0, H, tid, p.vecB);
+        if (nu < 32) {                         // ragged last unit tile: valid rows are x with (x % 32) < nu
+#pragma unroll
+            for (int r = 0; r < LB::NV; ++r) {
+                const int x = tid / KL + LB::XR * r;
+                lb.xoff[r] = (x < 96 && (x & 31) < nu) ? rb.off(x) : -1;
+            }
+            lb.fast = false;
+        }
+        const int li = lane & 31, lk = lane >> 5;
+        const int nkt = (H + BKT - 1) / BKT;
+        float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
+        la.load(ra0, hprev, ra, m0, B, 0, H, tid, p.vecA);
+        lb.load(rb0, Wb, rb, 0, 96, 0, H, tid, p.vecB);
+        if (nkt > 1) {
+            la.load(ra1, hprev, ra, m0, B, BKT, H, tid, p.vecA);
+            lb.load(rb1, Wb, rb, 0, 96, BKT, H, tid, p.vecB);
+        }
+        la.store(ra0, As[0], tid);
+        lb.store(rb0, Bs[0], tid);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 2 < nkt) {
+                la.load(ra0, hprev, ra, m0, B, (kt + 2) * BKT, H, tid, p.vecA);
+                lb.load(rb0, Wb, rb, 0, 96, (kt + 2) * BKT, H, tid, p.vecB);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BKT; kk += 2) {
+                const float a = As[buf][kk + lk][wave * 32 + li];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[buf][kk + lk][g * 32 + li], acc[g], 0, 0, 0);
+            }
+            if (kt + 1 < nkt) {
+                la.store(ra1, As[buf ^ 1], tid);
+                lb.store(rb1, Bs[buf ^ 1], tid);
+#pragma unroll
+                for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
+#pragma unroll
+                for (int r = 0; r < LB::NV; ++r) rb1[r] = rb0[r];
+            }
+            __syncthreads();
+        }
+        // gates: lane (li, lk) holds unit j0 + li of trials m0 + 32*wave + (r&3) + 8*(r>>2) + 4*lk
+        const int j = j0 + li;
+        if (j < H) {
+            const float* bh = p.b_hh[dir];
+            const float b_r = bh[j], b_z = bh[H + j], b_n = bh[2 * H + j];
+            const float* gi = p.gi + ((long long)dir * T + t) * B * 3 * H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (b < B) {
+                    const float* gp = gi + (long long)b * 3 * H;
+                    const float rg = sigmoidf_acc(gp[j] + acc[0][r] + b_r);
+                    const float zg = sigmoidf_acc(gp[H + j] + acc[1][r] + b_z);
+                    const float q = acc[2][r] + b_n;
+                    const float ng = tanhf(gp[2 * H + j] + rg * q);
+                    const float hp = hprev[(long long)b * ldy + j];
+                    p.y_ext[((long long)(t + 1) * B + b) * ldy + dir * H + j] = ng + zg * (hp - ng);
+                    if (p.saved) {
+                        float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H;
+                        sv[j] = rg; sv[H + j] = zg; sv[2 * H + j] = ng; sv[3 * H + j] = q;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// h0 slots of y_ext (slot 0 / slot T+1) for the per-step path
+__global__ void gru_init_slots_kernel(const float* __restrict__ h0, float* __restrict__ y_ext, int T, int B, int H, int ndir) {
+    const long long n = (long long)ndir * B * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int dir = (int)(i / ((long long)B * H));
+        const long long rem = i % ((long long)B * H);
+        const int b = (int)(rem / H), k = (int)(rem % H);
+        const int slot_h0 = (dir == 0) ? 0 : T + 1, slot_other = (dir == 0) ? T + 1 : 0;
+        const int ldy = ndir * H;
+        y_ext[((long long)slot_h0 * B + b) * ldy + dir * H + k] = h0 ? h0[i] : 0.f;
+        y_ext[((long long)slot_other * B + b) * ldy + dir * H + k] = 0.f;
+    }
+}
+
+// Backward, one launch per step (reverse processing order).  GEMM part: M = dgh_{next} W_hh with
+// dgh_{next} = [dgi_next(:, 0:2H) | dghn_next] (two k segments) on 64 x 128 tiles; epilogue: dh = dy_t +
+// keep_next + M, gate gradients of step t -> dgi_t, dghn_t, keep_t (= z * dh).  first = 1: no GEMM, the
+// running gradient starts from dhn (or zero).  final = 1: only dh0 = keep + M is written.
+struct GruStepBwd {
+    const float* dy;        // (T, B, ndir*H) or null
+    const float* dhn;       // (ndir, B, H) or null
+    const float* y_ext;
+    const float* saved;
+    const float* w_hh[2];   // (3H x H): B operand [k][n]
+    float* dgi;             // (ndir, T, B, 3H)
+    float* dghn;            // (ndir, T, B, H)
+    float* keep_in;         // (ndir, B, H)  z*dh of the step processed before (next in time order)
+    float* keep_out;
+    float* dh0;             // (ndir, B, H), final pass only
+    int T, B, H, ndir, s, first, final;
+    int vecA1, vecA2, vecB;
+};
+
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruStepBwd p) {
+    using namespace xps_tile;
+    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    const int dir = blockIdx.z, H = p.H, B = p.B, T = p.T;
+    const int ldy = p.ndir * H;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc[1][2];
+    zero_acc<1>(acc);
+    if (!p.first) {
+        // step processed just before this one (one step LATER in processing order)
+        const int sn = p.final ? 0 : p.s + 1;
+        const int tn = (dir == 0) ? sn : T - 1 - sn;
+        const float* A1 = p.dgi + (((long long)dir * T + tn) * B) * 3 * H;       // (B x 2H of 3H)
+        const float* A2 = p.dghn + (((long long)dir * T + tn) * B) * H;          // (B x H)
+        RowMap r1; r1.gs = 0; r1.ld = 3 * H; r1.rpg = 1 << 30;
+        RowMap r2; r2.gs = 0; r2.ld = H; r2.rpg = 1 << 30;
+        RowMap rb; rb.gs = 0; rb.ld = H; rb.rpg = 1 << 30;
+        const float* W = p.w_hh[dir];
+        gemm_accumulate<true, false, 1>(acc, nullptr, A1, r1, W, rb, B, H, 2 * H, m0, n0, 0, 2 * H, p.vecA1, p.vecB, As, Bs);
+        gemm_accumulate<true, false, 1>(acc, nullptr, A2, r2, W + (long long)2 * H * H, rb, B, H, H, m0, n0, 0, H, p.vecA2, p.vecB, As, Bs);
+    }
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    const int li = lane & 31, lk = lane >> 5;
+    const int t = (dir == 0) ? p.s : T - 1 - p.s;
+    const int slot_prev = (dir == 0) ? t : t + 2;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int j = n0 + wn + jn * 32 + li;
+        if (j >= H) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (b >= B) continue;
+            const long long ob = ((long long)dir * B + b) * H + j;
+            float dh = acc[0][jn][r];
+            if (p.first) dh = p.dhn ? p.dhn[ob] : 0.f;
+            else dh += p.keep_in[ob];
+            if (p.final) { p.dh0[ob] = dh; continue; }
+            if (p.dy) dh += p.dy[((long long)t * B + b) * ldy + dir * H + j];
+            const float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H;
+            const float rg = sv[j], zg = sv[H + j], ng = sv[2 * H + j], q = sv[3 * H + j];
+            const float hp = p.y_ext[((long long)slot_prev * B + b) * ldy + dir * H + j];
+            const float dn = dh * (1.f - zg);
+            const float dz = dh * (hp - ng);
+            const float dan = dn * (1.f - ng * ng);
+            const long long o = (((long long)dir * T + t) * B + b) * 3 * H;
+            p.dgi[o + j] = dan * q * rg * (1.f - rg);
+            p.dgi[o + H + j] = dz * zg * (1.f - zg);
+            p.dgi[o + 2 * H + j] = dan;
+            p.dghn[(((long long)dir * T + t) * B + b) * H + j] = dan * rg;
+            p.keep_out[ob] = dh * zg;
+        }
+    }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -729,6 +939,12 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// XPS_GRU_STEP_PATH=0 forces the streaming persistent kernels for H > 128 (A/B comparisons)
+inline bool use_step_path() {
+    static const bool on = [] { const char* e = getenv("XPS_GRU_STEP_PATH"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 }  // namespace
 
@@ -752,6 +968,24 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     }
     const size_t lds_bytes = (size_t)2 * GBM * p.ldh * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident state tile");
+    if (H > 128 && use_step_path()) {
+        // large hidden size: one fused GEMM + gate launch per time step (see gru_step_fwd_kernel)
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(gru_init_slots_kernel, dim3(cdiv((long long)ndir * B * H, 256) > 1024 ? 1024 : cdiv((long long)ndir * B * H, 256)),
+                           dim3(256), 0, st, h0, y_ext, T, B, H, ndir);
+        GruStepFwd q;
+        q.gi = gi; q.y_ext = y_ext; q.saved = saved; q.T = T; q.B = B; q.H = H; q.ndir = ndir;
+        for (int d = 0; d < 2; ++d) { q.w_hh[d] = p.w_hh[d]; q.b_hh[d] = p.b_hh[d]; }
+        q.vecA = (int)(H % 4 == 0 && aligned16(y_ext));
+        q.vecB = (int)vec;
+        dim3 sgrid(cdiv(H, 32), cdiv(B, 128), ndir);
+        for (int s = 0; s < T; ++s) {
+            q.s = s;
+            hipLaunchKernelGGL(gru_step_fwd_kernel, sgrid, dim3(256), 0, st, q);
+        }
+        XPS_CHECK_LAUNCH();
+        return XPS_OK;
+    }
     dim3 grid(cdiv(B, GBM), ndir);
     if (vec && (H == 128 || H == 64)) {
         if (H == 128) hipLaunchKernelGGL(gru_fwd_resident_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -772,10 +1006,16 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     return XPS_OK;
 }
 
+extern "C" size_t xps_gru_seq_bwd_f32_workspace(int T, int B, int H, int ndir) {
+    (void)T;
+    if (B <= 0 || H <= 0 || ndir <= 0) return 16;
+    return (size_t)2 * ndir * B * H * sizeof(float) + 16;       // ping-pong running gradient of the per-step path
+}
+
 extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
-                                   const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
-                                   int T, int B, int H, int ndir, void* stream) {
-    XPS_CHECK_ARG(y_ext && saved && w_hh_t && dgi && dghn, "null argument");
+                                   const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                                   int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(y_ext && saved && w_hh && w_hh_t && dgi && dghn, "null argument");
     XPS_CHECK_ARG(dy || dhn, "at least one of dy / dhn must be given");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
@@ -793,6 +1033,40 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
     }
     const size_t lds_bytes = (size_t)GBM * (p.ldg + p.ldc) * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident gradient tile");
+    if (H > 128 && use_step_path()) {
+        if (!workspace || workspace_bytes < xps_gru_seq_bwd_f32_workspace(T, B, H, ndir) || !aligned16(workspace)) {
+            xps_set_error("xps_gru_seq_bwd_f32: workspace too small or misaligned");
+            return XPS_E_WORKSPACE;
+        }
+        hipStream_t st = (hipStream_t)stream;
+        GruStepBwd q;
+        q.dy = dy; q.dhn = dhn; q.y_ext = y_ext; q.saved = saved; q.dgi = dgi; q.dghn = dghn; q.dh0 = dh0;
+        q.T = T; q.B = B; q.H = H; q.ndir = ndir;
+        bool vb = (H % 4 == 0);
+        for (int d = 0; d < 2; ++d) {
+            q.w_hh[d] = w_hh[d < ndir ? d : 0];
+            XPS_CHECK_ARG(q.w_hh[d], "null weight pointer");
+            vb = vb && aligned16(q.w_hh[d]);
+        }
+        q.vecB = (int)vb;
+        q.vecA1 = (int)(H % 4 == 0 && aligned16(dgi));
+        q.vecA2 = (int)(H % 4 == 0 && aligned16(dghn));
+        float* keep[2] = {(float*)workspace, (float*)workspace + (size_t)ndir * B * H};
+        dim3 sgrid(cdiv(H, 128), cdiv(B, 64), ndir);
+        int pp = 0;
+        for (int s = T - 1; s >= 0; --s) {
+            q.s = s; q.first = (s == T - 1); q.final = 0;
+            q.keep_in = keep[pp]; q.keep_out = keep[pp ^ 1];
+            hipLaunchKernelGGL(gru_step_bwd_kernel, sgrid, dim3(256), 0, st, q);
+            pp ^= 1;
+        }
+        if (dh0) {
+            q.s = 0; q.first = 0; q.final = 1; q.keep_in = keep[pp]; q.keep_out = keep[pp ^ 1];
+            hipLaunchKernelGGL(gru_step_bwd_kernel, sgrid, dim3(256), 0, st, q);
+        }
+        XPS_CHECK_LAUNCH();
+        return XPS_OK;
+    }
     dim3 grid(cdiv(B, GBM), ndir);
     if (vec && (H == 128 || H == 64)) {
         if (H == 128) hipLaunchKernelGGL(gru_bwd_resident_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);

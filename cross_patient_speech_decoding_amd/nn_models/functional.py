@@ -197,8 +197,10 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
     dgi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
     dghn = torch.empty(ndir, T, B, H, dtype=_f32, device=dev)
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
-    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_t), _ptr(dgi), _ptr(dghn),
-         _ptr(dh0), T, B, H, ndir, _stream())
+    nbytes = lib().xps_gru_seq_bwd_f32_workspace(T, B, H, ndir)
+    ws = _ws(nbytes, dev)
+    call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
+         _ptr(dghn), _ptr(dh0), T, B, H, ndir, _ptr(ws), nbytes, _stream())
     return dgi, dghn, dh0
 
 

@@ -123,14 +123,17 @@ int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* 
  *   dhn    [ndir][B][H]     gradient w.r.t. the FINAL hidden state of each direction (h at t = T-1 forward,
  *                           t = 0 reverse), or NULL; it seeds the running dh, so a layer whose per-step
  *                           output is unused downstream needs no dy buffer at all
- *   w_hh_t [ndir] pointers to W_hh^T (H x 3H), see xps_transpose_f32
+ *   w_hh   [ndir] pointers to W_hh (3H x H) and  w_hh_t [ndir] pointers to W_hh^T (H x 3H, see
+ *          xps_transpose_f32): H <= 128 keeps W_hh^T resident in registers for all steps; larger H runs one
+ *          fused GEMM + gate-gradient launch per step on W_hh (workspace: xps_gru_seq_bwd_f32_workspace)
  *   dgi    [ndir][T][B][3H] gradient w.r.t. gi   (= w.r.t. input pre-activations r, z, n)
  *   dghn   [ndir][T][B][H]  n-gate part of the gradient w.r.t. (h_{t-1} W_hh^T + b_hh); its r and z
  *                           parts equal those of dgi, so they are not stored twice
  *   dh0    [ndir][B][H]     gradient w.r.t. h0 (or NULL)                       */
+size_t xps_gru_seq_bwd_f32_workspace(int T, int B, int H, int ndir);
 int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
-                        const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
-                        int T, int B, int H, int ndir, void* stream);
+                        const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                        int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
 
 int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
 

@@ -116,7 +116,7 @@ def _weights(gru, ndir):
 
 
 @pytest.mark.parametrize('T,B,In,H,ndir', [(1, 5, 6, 16, 1), (7, 5, 6, 16, 2), (4, 33, 9, 20, 2), (20, 40, 100, 128, 2),
-                                           (3, 17, 8, 6, 2), (5, 16, 12, 500, 1), (6, 21, 10, 64, 2), (9, 130, 24, 128, 1)])
+                                           (3, 17, 8, 6, 2), (5, 16, 12, 500, 1), (6, 21, 10, 64, 2), (9, 130, 24, 128, 1), (4, 150, 40, 256, 2), (3, 70, 24, 200, 2), (2, 33, 16, 132, 1)])
 def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir):
     torch.set_num_threads(4)
     gru = _cpu_gru(In, H, ndir, seed=T * 100 + H)
