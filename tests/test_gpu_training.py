@@ -136,3 +136,28 @@ def test_train_seq2seq_cli_end_to_end(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     accs = np.load(os.path.join(str(tmp_path), 'accs', 'SYN', 'SYN_pooled_accs.npy'))
     assert accs.shape == (1, 2) and accs.mean() > 0.15            # chance 1/9
+
+
+def test_config3_mcca_aligned_cross_patient_training():
+    """BASELINE config 3 in miniature: 3 patients -> per-patient PCA -> ONE multiview MCCA (device) -> pooled
+    trials -> seq2seq GRU trained by the HIP trainer; k-fold DataModule in multiview mode."""
+    from cross_patient_speech_decoding_amd.alignment import AlignMCCA
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    from cross_patient_speech_decoding_amd.nn_models.data_utils.datamodules import AlignedMicroValDataModule
+    from cross_patient_speech_decoding_amd.nn_models.trainer import Trainer, seed_everything
+    seed_everything(1)
+    views = _pooled_views(P=3, N=120, T=60, C=(20, 16, 18), n_cond=10)
+    (Xt, yt), pool = views[0], [(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(y)) for x, y in views[1:]]
+    dm = AlignedMicroValDataModule(torch.from_numpy(Xt), torch.from_numpy(yt), torch.from_numpy(yt), pool,
+                                   lambda: AlignMCCA(n_components=6, regs=0.5), batch_size=5000, folds=3, val_size=0.2,
+                                   multiview=True)
+    dm.setup()
+    dm.set_fold(0)
+    shape = dm.get_data_shape()
+    assert shape[1:] == (60, 6) and shape[0] > 150                   # pooled over the three patients
+    model = Seq2SeqRNN(6, 16, 32, 9, 2, 1, 6, 6, 0, 0.1, 0.1, 'gru', 5e-3, 1e-5, activation=False, decay_iters=30)
+    trainer = Trainer(max_epochs=30, gradient_clip_val=0.5)
+    trainer.fit(model, dm.train_dataloader(), dm.val_dataloader())
+    trainer.test(model, dm.test_dataloader())
+    m = trainer.logged_metrics
+    assert m['train_loss'] < 2.0 and m['test_acc'] > 0.15           # chance: ln 9 = 2.197 / 0.111
