@@ -251,7 +251,7 @@ def main():
             out['roofline'] = time_dominant_kernel(model, c)
         else:
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
-        if world == 1 and not args.no_cpu_baseline and not explore:
+        if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(c)
         print(json.dumps(out), flush=True)
     if world > 1:

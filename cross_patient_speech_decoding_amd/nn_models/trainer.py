@@ -61,6 +61,7 @@ class FlatAdamW:
                 self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+        self._grad_views = [p.grad for p in self.params]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.base_lr = self.lr = lr
         self.betas, self.eps, self.weight_decay, self.max_norm = betas, eps, weight_decay, max_norm
@@ -75,6 +76,15 @@ class FlatAdamW:
         """all-reduce (mean) -> global grad norm -> fused clip + AdamW.  Returns the pre-clip norm
         (device scalar, like clip_grad_norm_)."""
         world, _ = _world(self.group)
+        # robustness: if someone reset .grad (model.zero_grad(set_to_none=True)) autograd allocated fresh
+        # gradient tensors; fold them back into the flat buffer and restore the views
+        for p, view in zip(self.params, self._grad_views):
+            if p.grad is None:
+                view.zero_()
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
         if world > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_g.mul_(1.0 / world)
