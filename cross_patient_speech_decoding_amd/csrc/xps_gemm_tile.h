@@ -62,12 +62,17 @@ struct TileLoader {
         }
     }
 
+    // unguarded 16-byte loads of a FULL k-tile (only valid when `fast`)
+    __device__ inline void load_fast(float4 (&v)[NV], int kt0) const {
+#pragma unroll
+        for (int r = 0; r < NV; ++r)
+            v[r] = *reinterpret_cast<const float4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
+    }
+
     __device__ inline void load(float4 (&v)[NV], const float* __restrict__ P, const RowMap& rm, int x0, int X,
                                 int kt0, int kend, int tid, bool vec) const {
         if (fast && kt0 + BKT <= kend) {
-#pragma unroll
-            for (int r = 0; r < NV; ++r)
-                v[r] = *reinterpret_cast<const float4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
+            load_fast(v, kt0);
             return;
         }
         if (KCONTIG) {
@@ -133,30 +138,30 @@ struct TileLoader {
 // acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Pipeline: global
 // loads run TWO k-tiles ahead of the MFMAs (registers), LDS is double buffered, one barrier per k-tile.
 // csum (TN form, optional): running column sums of the staged A tile (bias gradient).
-template <bool AK, bool BK, int MI>
-__device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
-                                       const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
-                                       int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
-                                       float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
+template <bool AK, bool BK, int MI, bool FAST>
+__device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float* csum,
+                                     const TileLoader<AK, 64 * MI>& la, const TileLoader<BK, 128>& lb,
+                                     const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
+                                     int M, int N, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
+                                     float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
     constexpr int WM = 64 * MI;
     using LA = TileLoader<AK, WM>;
     using LB = TileLoader<BK, 128>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    LA la;
-    LB lb;
-    la.init(A, ra, m0, M, K, tid, vecA);
-    lb.init(B, rb, n0, N, K, tid, vecB);
+    // FAST: every k-tile in [kbeg, kend) is full and both operand tiles are interior + aligned: the k loop has
+    // no guards and no divergent paths, so the compiler's waitcnt placement keeps two k-tiles of loads in flight
+    // (a loop that also contains the guarded path gets conservative vmcnt(0) waits at every join)
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
     const int li = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BKT - 1) / BKT;
 
     float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
-        la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA);
-        lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB);
+        if (FAST) { la.load_fast(ra0, kbeg); lb.load_fast(rb0, kbeg); }
+        else { la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB); }
         if (nkt > 1) {
-            la.load(ra1, A, ra, m0, M, kbeg + BKT, kend, tid, vecA);
-            lb.load(rb1, B, rb, n0, N, kbeg + BKT, kend, tid, vecB);
+            if (FAST) { la.load_fast(ra1, kbeg + BKT); lb.load_fast(rb1, kbeg + BKT); }
+            else { la.load(ra1, A, ra, m0, M, kbeg + BKT, kend, tid, vecA); lb.load(rb1, B, rb, n0, N, kbeg + BKT, kend, tid, vecB); }
         }
         la.store(ra0, As[0], tid);
         lb.store(rb0, Bs[0], tid);
@@ -170,8 +175,8 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
         const int buf = kt & 1;
         GSTAMP(g0)
         if (kt + 2 < nkt) {
-            la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA);
-            lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB);
+            if (FAST) { la.load_fast(ra0, kbeg + (kt + 2) * BKT); lb.load_fast(rb0, kbeg + (kt + 2) * BKT); }
+            else { la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB); }
         }
         GSTAMP(g1)
 #pragma unroll
@@ -215,6 +220,29 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
         g_gstamp[wid * 4 + 0] = s_ld; g_gstamp[wid * 4 + 1] = s_mm; g_gstamp[wid * 4 + 2] = s_st; g_gstamp[wid * 4 + 3] = s_bar;
     }
 #endif
+}
+
+// acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Interior, aligned
+// tiles run the unguarded pipeline over all full k-tiles and the guarded one only over a ragged k tail.
+template <bool AK, bool BK, int MI>
+__device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
+                                       const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
+                                       int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
+                                       float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
+    TileLoader<AK, 64 * MI> la;
+    TileLoader<BK, 128> lb;
+    la.init(A, ra, m0, M, K, threadIdx.x, vecA);
+    lb.init(B, rb, n0, N, K, threadIdx.x, vecB);
+    const int kfull = kbeg + ((kend - kbeg) / BKT) * BKT;
+    // the split pays for the k-contiguous ([x][k]) operand form, whose guarded path is long (partial vector
+    // loads with their own waits); the [k][x] form is faster with the single combined loop
+    if (AK && BK && la.fast && lb.fast && kfull > kbeg) {
+        gemm_pipeline<AK, BK, MI, true>(acc, csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
+        if (kfull < kend)
+            gemm_pipeline<AK, BK, MI, false>(acc, csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
+    } else {
+        gemm_pipeline<AK, BK, MI, false>(acc, csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
+    }
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
