@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * BN;
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
-    gemm_accumulate<AK, BK, MI>(acc, nullptr, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
-    if (A2) gemm_accumulate<AK, BK, MI>(acc, nullptr, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
+    float nocs = 0.f;
+    gemm_accumulate<AK, BK, MI>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
+    if (A2) gemm_accumulate<AK, BK, MI>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
     gemm_store<MI>(acc, C + (long long)blockIdx.z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * BN;
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
-    gemm_accumulate<true, true, MI>(acc, nullptr, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, As, Bs);
+    float nocs = 0.f;
+    gemm_accumulate<true, true, MI>(acc, nocs, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, As, Bs);
     gemm_store<MI>(acc, pm.C[z], rc, pm.bias[z], M, N, m0, n0, 0);
 }
 
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     f32x16 acc[2][2];
     zero_acc<2>(acc);
     float csum = 0.f;
-    gemm_accumulate<false, false, 2>(acc, cs ? &csum : nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
+    gemm_accumulate<false, false, 2>(acc, csum, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
                                      kbeg, kend, P.vecA, P.vecB, As, Bs);
     gemm_store<2>(acc, slab, rs, nullptr, P.M, P.N, tm * BM, tn * BN, 0);
     if (cs) {                                   // fold the two k-groups of the column sums through LDS

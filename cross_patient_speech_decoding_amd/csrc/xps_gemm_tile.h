@@ -63,13 +63,13 @@ struct TileLoader {
     }
 
     // unguarded 16-byte loads of a FULL k-tile (only valid when `fast`)
-    __device__ inline void load_fast(float4 (&v)[NV], int kt0) const {
+    __device__ inline void load_fast(f32x4 (&v)[NV], int kt0) const {
 #pragma unroll
         for (int r = 0; r < NV; ++r)
-            v[r] = *reinterpret_cast<const float4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
+            v[r] = *reinterpret_cast<const f32x4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
     }
 
-    __device__ inline void load(float4 (&v)[NV], const float* __restrict__ P, const RowMap& rm, int x0, int X,
+    __device__ inline void load(f32x4 (&v)[NV], const float* __restrict__ P, const RowMap& rm, int x0, int X,
                                 int kt0, int kend, int tid, bool vec) const {
         if (fast && kt0 + BKT <= kend) {
             load_fast(v, kt0);
@@ -79,11 +79,11 @@ struct TileLoader {
             const int k = kt0 + (tid % KL) * 4;
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (xoff[r] >= 0) {
                     const float* p = P + xoff[r] + k;
                     if (vec && k + 3 < kend) {
-                        t = *reinterpret_cast<const float4*>(p);
+                        t = *reinterpret_cast<const f32x4*>(p);
                     } else {
                         if (k + 0 < kend) t.x = p[0];
                         if (k + 1 < kend) t.y = p[1];
@@ -98,11 +98,11 @@ struct TileLoader {
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 const int k = kt0 + tid / XL + KR * r;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < kend && x < X) {
                     const float* p = P + rm.off(k) + x;
                     if (vec && x + 3 < X) {
-                        t = *reinterpret_cast<const float4*>(p);
+                        t = *reinterpret_cast<const f32x4*>(p);
                     } else {
                         t.x = p[0];
                         if (x + 1 < X) t.y = p[1];
@@ -115,7 +115,7 @@ struct TileLoader {
         }
     }
 
-    __device__ inline void store(const float4 (&v)[NV], float (*S)[LDT], int tid) const {
+    __device__ inline void store(const f32x4 (&v)[NV], float (*S)[LDT], int tid) const {
         if (KCONTIG) {
             const int k4 = (tid % KL) * 4;
 #pragma unroll
@@ -130,7 +130,7 @@ struct TileLoader {
             const int x4 = (tid % XL) * 4;
 #pragma unroll
             for (int r = 0; r < NV; ++r)
-                *reinterpret_cast<float4*>(&S[tid / XL + KR * r][x4]) = v[r];
+                *reinterpret_cast<f32x4*>(&S[tid / XL + KR * r][x4]) = v[r];
         }
     }
 };
@@ -139,7 +139,7 @@ struct TileLoader {
 // loads run TWO k-tiles ahead of the MFMAs (registers), LDS is double buffered, one barrier per k-tile.
 // csum (TN form, optional): running column sums of the staged A tile (bias gradient).
 template <bool AK, bool BK, int MI, bool FAST>
-__device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float* csum,
+__device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
                                      const TileLoader<AK, 64 * MI>& la, const TileLoader<BK, 128>& lb,
                                      const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                      int M, int N, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
@@ -155,7 +155,7 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float* csum,
     const int li = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BKT - 1) / BKT;
 
-    float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
+    f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
         if (FAST) { la.load_fast(ra0, kbeg); lb.load_fast(rb0, kbeg); }
         else { la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB); }
@@ -192,11 +192,11 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float* csum,
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (csum) {
+        if (want_csum) {
             constexpr int G = 256 / WM, KG = BKT / G;          // k groups and rows per group
             const int cm = tid % WM, kh = (tid / WM) * KG;
 #pragma unroll
-            for (int kk = 0; kk < KG; ++kk) *csum += As[buf][kh + kk][cm];
+            for (int kk = 0; kk < KG; ++kk) csum += As[buf][kh + kk][cm];
         }
         GSTAMP(g2)
         if (kt + 1 < nkt) {
@@ -225,7 +225,7 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float* csum,
 // acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Interior, aligned
 // tiles run the unguarded pipeline over all full k-tiles and the guarded one only over a ragged k tail.
 template <bool AK, bool BK, int MI>
-__device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
+__device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
                                        const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                        int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
                                        float (*As)[BKT][LDT], float (*Bs)[BKT][LDT]) {
@@ -237,11 +237,11 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float* csum,
     // the split pays for the k-contiguous ([x][k]) operand form, whose guarded path is long (partial vector
     // loads with their own waits); the [k][x] form is faster with the single combined loop
     if (AK && BK && la.fast && lb.fast && kfull > kbeg) {
-        gemm_pipeline<AK, BK, MI, true>(acc, csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
+        gemm_pipeline<AK, BK, MI, true>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
         if (kfull < kend)
-            gemm_pipeline<AK, BK, MI, false>(acc, csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
+            gemm_pipeline<AK, BK, MI, false>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
     } else {
-        gemm_pipeline<AK, BK, MI, false>(acc, csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
+        gemm_pipeline<AK, BK, MI, false>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
     }
 }
 

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
         }
         const int li = lane & 31, lk = lane >> 5;
         const int nkt = (H + BKT - 1) / BKT;
-        float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
+        f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
         la.load(ra0, hprev, ra, m0, B, 0, H, tid, p.vecA);
         lb.load(rb0, Wb, rb, 0, 96, 0, H, tid, p.vecB);
         if (nkt > 1) {
@@ -886,9 +886,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruStepBwd p) {
         RowMap r1; r1.gs = 0; r1.ld = 3 * H; r1.rpg = 1 << 30;
         RowMap r2; r2.gs = 0; r2.ld = H; r2.rpg = 1 << 30;
         RowMap rb; rb.gs = 0; rb.ld = H; rb.rpg = 1 << 30;
+        float nocs = 0.f;
         const float* W = p.w_hh[dir];
-        gemm_accumulate<true, false, 1>(acc, nullptr, A1, r1, W, rb, B, H, 2 * H, m0, n0, 0, 2 * H, p.vecA1, p.vecB, As, Bs);
-        gemm_accumulate<true, false, 1>(acc, nullptr, A2, r2, W + (long long)2 * H * H, rb, B, H, H, m0, n0, 0, H, p.vecA2, p.vecB, As, Bs);
+        gemm_accumulate<true, false, 1>(acc, nocs, false, A1, r1, W, rb, B, H, 2 * H, m0, n0, 0, 2 * H, p.vecA1, p.vecB, As, Bs);
+        gemm_accumulate<true, false, 1>(acc, nocs, false, A2, r2, W + (long long)2 * H * H, rb, B, H, H, m0, n0, 0, H, p.vecA2, p.vecB, As, Bs);
     }
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
     const int li = lane & 31, lk = lane >> 5;

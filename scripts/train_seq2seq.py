@@ -7,7 +7,7 @@ iteration structure and output files), driven by the HIP model, DataModules and 
     python -m torch.distributed.run --nproc-per-node 8 scripts/train_seq2seq.py -pt S14 -p True   # data parallel
 
 Extra (not in the reference): --synthetic N runs on seeded synthetic patients when the private
-~/data/pt_decoding_data_S62.pkl is not available; --iters/--folds/--epochs shrink the 50 x 20 x 500 schedule.
+~/data/pt_decoding_data_S62.pkl is not available; --seed fixes folds/augmentations/initialisation; --iters/--folds/--epochs shrink the 50 x 20 x 500 schedule.
 """
 import argparse
 import csv
@@ -38,6 +38,7 @@ def init_parser():
     parser.add_argument('--iters', type=int, default=50)
     parser.add_argument('--folds', type=int, default=20)
     parser.add_argument('--epochs', type=int, default=500)
+    parser.add_argument('--seed', type=int, default=None, help='seed folds/augmentations/initialisation (reference: unseeded)')
     parser.add_argument('--hidden', type=int, default=500)
     parser.add_argument('--out', type=str, default='~/workspace/nn_data')
     return parser
@@ -98,8 +99,8 @@ def seq2seq_decoding():
     for i in range(args.iters):
         if rank == 0:
             print(f'##### Setting up data module for iteration {i + 1} #####', flush=True)
-        if dist.is_initialized():                  # identical folds / augmentations on every rank
-            L.seed_everything(1000 + i)
+        if dist.is_initialized() or args.seed is not None:   # identical folds / augmentations on every rank
+            L.seed_everything((args.seed if args.seed is not None else 1000) + i)
         dm.setup()
         fold_accs = []
         for fold in range(n_folds):

@@ -131,11 +131,11 @@ def test_data_parallel_two_ranks_equal_single_process():
 def test_train_seq2seq_cli_end_to_end(tmp_path):
     """The counterpart of scripts/train_seq2seq.py: pooled + CCA-aligned k-fold training on synthetic patients."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train_seq2seq.py'), '-pt', 'SYN', '-p', 'True',
-                          '--synthetic', '3', '--iters', '1', '--folds', '2', '--epochs', '15', '--hidden', '64',
+                          '--synthetic', '3', '--iters', '1', '--folds', '2', '--epochs', '60', '--hidden', '64', '--seed', '3',
                           '--out', str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     accs = np.load(os.path.join(str(tmp_path), 'accs', 'SYN', 'SYN_pooled_accs.npy'))
-    assert accs.shape == (1, 2) and accs.mean() > 0.15            # chance 1/9
+    assert accs.shape == (1, 2) and accs.mean() > 0.2             # chance 1/9
 
 
 def test_config3_mcca_aligned_cross_patient_training():
