@@ -161,3 +161,34 @@ def test_config3_mcca_aligned_cross_patient_training():
     trainer.test(model, dm.test_dataloader())
     m = trainer.logged_metrics
     assert m['train_loss'] < 2.0 and m['test_acc'] > 0.15           # chance: ln 9 = 2.197 / 0.111
+
+
+@pytest.mark.parametrize('H,B,C', [(64, 150, 48), (128, 512, 64), (160, 96, 40)])
+def test_training_steps_are_bitwise_reproducible(H, B, C):
+    """No atomics anywhere on the path (split-K slabs, two-stage reductions, counter-based dropout): the same
+    seed gives the same bits, step after step -- what makes N-GPU runs comparable with 1-GPU runs."""
+    from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW, seed_everything
+
+    def run():
+        seed_everything(7)
+        XF._DROP_COUNTER[0] = 0
+        m = Seq2SeqRNN(C, 60, H, 10, 2, 1, 10, 10, 0, 0.3, 0.3, 'gru', 1e-3, 1e-5).cuda()
+        opt = FlatAdamW(m, lr=1e-3, max_norm=0.5)
+        x = torch.randn(B, 200, C).cuda()
+        y = torch.randint(1, 10, (B, 3)).cuda()
+        m.train()
+        trail = []
+        for s in range(3):
+            opt.zero_grad()
+            loss = m.training_step((x, y), s)
+            loss.backward()
+            g = opt.flat_g.clone()
+            opt.step()
+            trail.append((loss.detach().clone(), g, opt.flat_p.clone()))
+        return trail
+
+    a, b = run(), run()
+    for (la, ga, pa), (lb, gb, pb) in zip(a, b):
+        assert torch.equal(la, lb) and torch.equal(ga, gb) and torch.equal(pa, pb)
