@@ -31,15 +31,19 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     int M, int N, int K, int kchunk, long long slab_stride, int accumulate, int vecA, int vecB) {
     __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
-    const int kbeg = blockIdx.z * kchunk;
+    // 1-D grid, logical order (k-split, m-tile, n-tile): the n-tiles of an A panel run on one XCD
+    const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + 64 * MI - 1) / (64 * MI));
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = lid / tiles, t = lid % tiles;
+    const int kbeg = z * kchunk;
     const int kend = min(K, kbeg + kchunk);
-    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * BN;
+    const int m0 = (t / tiles_n) * (64 * MI), n0 = (t % tiles_n) * BN;
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
     gemm_accumulate<AK, BK, MI>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
     if (A2) gemm_accumulate<AK, BK, MI>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
-    gemm_store<MI>(acc, C + (long long)blockIdx.z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
+    gemm_store<MI>(acc, C + (long long)z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
 // Same A, up to 4 different (B, bias, C): the input projections of all directions of a layer in ONE launch
@@ -51,11 +55,16 @@ struct NtMulti {
 };
 template <int MI>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
-    const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int vecA, int vecB) {
+    const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int nprob,
+    int vecA, int vecB) {
     __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
-    const int z = blockIdx.z;
-    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * BN;
+    // logical order (m-tile, problem, n-tile): all blocks that read one A panel are neighbours on one XCD
+    const int tiles_n = (N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_m = nprob * tiles_n, rem = lid % per_m;
+    const int z = rem / tiles_n;
+    const int m0 = (lid / per_m) * (64 * MI), n0 = (rem % tiles_n) * BN;
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
@@ -86,12 +95,14 @@ struct TnGroup {
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    // logical order (problem, k-split, tile): the tiles of one k-chunk are neighbours on one XCD
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll 1
     for (int i = 1; i < g.n; ++i)
-        if ((int)blockIdx.x >= g.p[i].block_start) pi = i;
+        if (lid >= g.p[i].block_start) pi = i;
     const TnProb& P = g.p[pi];
-    const int local = blockIdx.x - P.block_start;
+    const int local = lid - P.block_start;
     const int Nout = P.N + (P.colsum ? 1 : 0);          // slab row = N products + 1 column sum
     const int tiles_m = (P.M + BM - 1) / BM;
     const int tile = local % (tiles_m * P.tiles_n), z = local / (tiles_m * P.tiles_n);
@@ -118,40 +129,67 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     }
 }
 
-__global__ void gemm_tn_grouped_reduce(TnGroup g, const float* __restrict__ ws) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= g.total_out) return;
+// Slab reduction.  One block = 64 consecutive outputs x 4 split lanes (one wave each): wave w sums slabs
+// w, w+4, ... with 8 loads in flight, then the four partial sums are folded in a fixed order through LDS
+// (deterministic: no atomics, the order depends only on the split count).
+constexpr int RED_OUT = 64;
+__device__ inline float slab_sum(const float* __restrict__ p, long long stride, int splits, int w) {
+    float s = 0.f;
+    int z = w;
+    for (; z + 28 < splits; z += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(z + 4 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; z += 4) s += p[(long long)z * stride];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const float* __restrict__ ws) {
+    __shared__ float part[4][RED_OUT];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * RED_OUT + l;
+    const bool live = idx < g.total_out;
     int pi = 0;
     long long base = 0;
+    if (live) {
 #pragma unroll 1
-    for (int i = 0; i < g.n; ++i) {
-        const long long sz = (long long)g.p[i].M * (g.p[i].N + (g.p[i].colsum ? 1 : 0));
-        if (idx < base + sz) { pi = i; break; }
-        base += sz;
+        for (int i = 0; i < g.n; ++i) {
+            const long long sz = (long long)g.p[i].M * (g.p[i].N + (g.p[i].colsum ? 1 : 0));
+            if (idx < base + sz) { pi = i; break; }
+            base += sz;
+        }
     }
     const TnProb& P = g.p[pi];
     const int Nout = P.N + (P.colsum ? 1 : 0);
     const long long e = idx - base;                       // [0, M*N): products, then M column sums
-    const float* sl = ws + P.slab_off + e;
-    const long long stride = (long long)P.M * Nout;
-    float s = 0.f;
-    for (int z = 0; z < P.splits; ++z) s += sl[z * stride];
-    const long long mn = (long long)P.M * P.N;
-    float* dst = (e < mn) ? (P.C + P.rc.off((int)(e / P.N)) + (int)(e % P.N)) : (P.colsum + (e - mn));
-    if (P.accumulate) s += *dst;
-    *dst = s;
+    part[w][l] = live ? slab_sum(ws + P.slab_off + e, (long long)P.M * Nout, P.splits, w) : 0.f;
+    __syncthreads();
+    if (w == 0 && live) {
+        float s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+        const long long mn = (long long)P.M * P.N;
+        float* dst = (e < mn) ? (P.C + P.rc.off((int)(e / P.N)) + (int)(e % P.N)) : (P.colsum + (e - mn));
+        if (P.accumulate) s += *dst;
+        *dst = s;
+    }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long slab_stride,
-                                     float* __restrict__ C, RowMap rc, int M, int N, int accumulate) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)M * N) return;
-    int m = (int)(idx / N), n = (int)(idx % N);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[(long long)z * slab_stride + idx];
-    float* p = C + rc.off(m) + n;
-    if (accumulate) s += *p;
-    *p = s;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long slab_stride,
+                                                            float* __restrict__ C, RowMap rc, int M, int N, int accumulate) {
+    __shared__ float part[4][RED_OUT];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * RED_OUT + l;
+    const bool live = idx < (long long)M * N;
+    part[w][l] = live ? slab_sum(slabs + idx, slab_stride, splits, w) : 0.f;
+    __syncthreads();
+    if (w == 0 && live) {
+        float s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+        float* p = C + rc.off((int)(idx / N)) + (int)(idx % N);
+        if (accumulate) s += *p;
+        *p = s;
+    }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -189,11 +227,11 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
     const int vecA = (int)(map_vec_ok(A, ra) && (!A2 || map_vec_ok(A2, ra)));
     const int vecB = (int)(map_vec_ok(B, rb) && (!B2 || map_vec_ok(B2, rb)));
     if (use_small_tiles(M, N)) {
-        dim3 grid(cdiv(N, BN), cdiv(M, 64), 1);
+        dim3 grid(cdiv(N, BN) * cdiv(M, 64));
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
                            M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
     } else {
-        dim3 grid(cdiv(N, BN), cdiv(M, 128), 1);
+        dim3 grid(cdiv(N, BN) * cdiv(M, 128));
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
                            M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
     }
@@ -247,11 +285,11 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
     }
     const int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
     if (use_small_tiles(M, N * nprob)) {
-        hipLaunchKernelGGL((gemm_nt_multi_kernel<1>), dim3(cdiv(N, BN), cdiv(M, 64), nprob), dim3(256), 0, (hipStream_t)stream,
-                           A, ra, pm, rb, rc, M, N, K, vecA, vecB);
+        hipLaunchKernelGGL((gemm_nt_multi_kernel<1>), dim3(cdiv(N, BN) * cdiv(M, 64) * nprob), dim3(256), 0, (hipStream_t)stream,
+                           A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
     } else {
-        hipLaunchKernelGGL((gemm_nt_multi_kernel<2>), dim3(cdiv(N, BN), cdiv(M, 128), nprob), dim3(256), 0, (hipStream_t)stream,
-                           A, ra, pm, rb, rc, M, N, K, vecA, vecB);
+        hipLaunchKernelGGL((gemm_nt_multi_kernel<2>), dim3(cdiv(N, BN) * cdiv(M, 128) * nprob), dim3(256), 0, (hipStream_t)stream,
+                           A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
     }
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -297,13 +335,13 @@ extern "C" int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra_, const floa
     RowMap rs;
     rs.gs = 0; rs.ld = N; rs.rpg = 1 << 30;
     const long long slab_stride = (long long)M * N;
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    dim3 grid(cdiv(N, BN) * cdiv(M, BM) * splits);
     hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, (hipStream_t)stream,
                        A, ra, B, rb, (const float*)nullptr, (const float*)nullptr, 0, slabs, rs, (const float*)nullptr,
                        M, N, K, kchunk, slab_stride, 0, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
     XPS_CHECK_LAUNCH();
     long long total = (long long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, RED_OUT)), dim3(256), 0, (hipStream_t)stream,
                        slabs, splits, slab_stride, C, rc, M, N, accumulate);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -378,7 +416,7 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     XPS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, 256)), dim3(256), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT)), dim3(256), 0, (hipStream_t)stream, g,
                        (const float*)workspace);
     XPS_CHECK_LAUNCH();
     return XPS_OK;

@@ -27,6 +27,16 @@ static __device__ unsigned long long g_gstamp[8192 * 4];
 
 constexpr int KL = BKT / 4;          // KCONTIG: lanes covering one row's k range
 
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with a private 4 MB L2), so
+// blocks b, b+8, b+16, ... share an L2.  The remap gives every XCD a CONTIGUOUS range of logical ids
+// (bijective for any grid size); kernels then order logical ids so that neighbours read the same operand
+// panel -> a panel is fetched from HBM / Infinity Cache once per XCD instead of once per block.
+__device__ inline int xcd_remap(int bid, int nwg) {
+    constexpr int NX = 8;
+    const int x = bid % NX, q = nwg / NX, r = nwg % NX;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / NX;
+}
+
 // Stages a (BKT x W) k-major tile of a matrix stored either [x][k] (KCONTIG) or [k][x]; W = 64 or 128.
 template <bool KCONTIG, int W>
 struct TileLoader {

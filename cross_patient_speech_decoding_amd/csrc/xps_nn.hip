@@ -35,16 +35,29 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X
     }
 }
 
-// stage 2: one block per 64 columns; four row-groups fold the partials in a fixed order, then combine
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, const float* __restrict__ part_sq,
-                                                     int nparts, int cols, float* __restrict__ out,
-                                                     float* __restrict__ out_sq, int accumulate) {
-    __shared__ float s1[4][64], s2[4][64];
+// stage 2: one 1024-thread block per 64 columns; sixteen row-groups fold the partials (8 loads in flight
+// each), then combine in a fixed order -- the result depends only on (rows, cols), never on timing
+constexpr int S2_GROUPS = 16;
+__global__ __launch_bounds__(1024) void colsum_stage2(const float* __restrict__ part, const float* __restrict__ part_sq,
+                                                      int nparts, int cols, float* __restrict__ out,
+                                                      float* __restrict__ out_sq, int accumulate) {
+    __shared__ float s1[S2_GROUPS][64], s2[S2_GROUPS][64];
     const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + l;
     float a = 0.f, a2 = 0.f;
     if (c < cols) {
-        for (int i = q; i < nparts; i += 4) {
+        int i = q;
+        for (; i + 7 * S2_GROUPS < nparts; i += 8 * S2_GROUPS) {
+            float v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = part[(long long)(i + u * S2_GROUPS) * cols + c];
+                w[u] = part_sq ? part_sq[(long long)(i + u * S2_GROUPS) * cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v[u]; a2 += w[u]; }
+        }
+        for (; i < nparts; i += S2_GROUPS) {
             a += part[(long long)i * cols + c];
             if (part_sq) a2 += part_sq[(long long)i * cols + c];
         }
@@ -53,8 +66,9 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
     s2[q][l] = a2;
     __syncthreads();
     if (q == 0 && c < cols) {
-        a = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
-        a2 = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
+        a = 0.f; a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < S2_GROUPS; ++k) { a += s1[k][l]; a2 += s2[k][l]; }
         if (accumulate) {
             a += out[c];
             if (out_sq) a2 += out_sq[c];
@@ -371,7 +385,7 @@ extern "C" int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, f
                            X, (long long)ldx, rows, cols, part, part_sq);
         XPS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(cols, 64)), dim3(1024), 0, (hipStream_t)stream,
                        part, part_sq, nparts, cols, out, out_sq, accumulate);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -432,7 +446,7 @@ extern "C" int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const 
     hipLaunchKernelGGL(bn_bwd_stage1, dim3(cdiv(F, 64), nparts), dim3(256), 0, (hipStream_t)stream,
                        dout, out, y, mean, rstd, drop_mask, drop_scale, relu, (long long)rows, F, part);
     XPS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(2 * F, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(2 * F, 64)), dim3(1024), 0, (hipStream_t)stream,
                        part, (const float*)nullptr, nparts, 2 * F, sums, (float*)nullptr, 0);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
