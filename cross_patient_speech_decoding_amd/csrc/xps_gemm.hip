@@ -46,6 +46,80 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     gemm_store<MI>(acc, C + (long long)z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
+// Few-row products (M <= 16: the decoder's token table E W_ih^T and its input gradient).  An MFMA tile
+// would be > 87 % padding and, with one or two blocks, pure load latency; here a block owns 64 columns x
+// 4 k-slices, every lane keeps all M accumulators, A values are wave-uniform loads, and the four k-slices
+// are folded through LDS in a fixed order.
+constexpr int SM_MAXM = 16;
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_small_kernel(
+    const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
+    const float* __restrict__ A2, const float* __restrict__ B2, int K2,
+    float* __restrict__ C, RowMap rc, const float* __restrict__ bias, int M, int N, int K, int accumulate, int vecB) {
+    __shared__ float red[4][SM_MAXM][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + l;
+    float acc[SM_MAXM];
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) acc[m] = 0.f;
+    long long aoff[SM_MAXM];
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) aoff[m] = AK ? ra.off(m < M ? m : 0) : (long long)(m < M ? m : 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* Ap = pass ? A2 : A;
+        const float* Bp = pass ? B2 : B;
+        const int Kp = pass ? K2 : K;
+        if (!Ap) break;
+        const int kq = (((Kp + 3) / 4) + 3) & ~3;               // k-slice length, multiple of 4
+        const int k0 = w * kq, k1 = min(Kp, k0 + kq);
+        if (n < N) {
+            const long long boff = BK ? rb.off(n) : (long long)n;
+            int k = k0;
+            if (BK && vecB) {
+                for (; k + 3 < k1; k += 4) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(Bp + boff + k);
+#pragma unroll
+                    for (int m = 0; m < SM_MAXM; ++m) {
+                        if (m < M) {
+                            if (AK) {
+                                const float* a = Ap + aoff[m] + k;
+                                acc[m] += a[0] * b.x; acc[m] += a[1] * b.y; acc[m] += a[2] * b.z; acc[m] += a[3] * b.w;
+                            } else {
+                                acc[m] += Ap[ra.off(k) + aoff[m]] * b.x; acc[m] += Ap[ra.off(k + 1) + aoff[m]] * b.y;
+                                acc[m] += Ap[ra.off(k + 2) + aoff[m]] * b.z; acc[m] += Ap[ra.off(k + 3) + aoff[m]] * b.w;
+                            }
+                        }
+                    }
+                }
+            }
+            for (; k < k1; ++k) {
+                const float b = BK ? Bp[boff + k] : Bp[rb.off(k) + boff];
+                const long long ak = AK ? (long long)k : ra.off(k);
+#pragma unroll
+                for (int m = 0; m < SM_MAXM; ++m)
+                    if (m < M) acc[m] += Ap[AK ? aoff[m] + ak : ak + aoff[m]] * b;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) red[w][m][l] = acc[m];
+    __syncthreads();
+    // 256 threads fold 16 x 64 outputs: thread -> (rows w, w+4, w+8, w+12; column l)
+    if (n < N) {
+#pragma unroll
+        for (int mm = 0; mm < SM_MAXM / 4; ++mm) {
+            const int m = w + 4 * mm;
+            if (m < M) {
+                float v = (red[0][m][l] + red[1][m][l]) + (red[2][m][l] + red[3][m][l]);
+                if (bias) v += bias[n];
+                float* c = C + rc.off(m) + n;
+                if (accumulate) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
 // Same A, up to 4 different (B, bias, C): the input projections of all directions of a layer in ONE launch
 // (blockIdx.z selects the problem) — twice the blocks per launch halves the under-filled tail round.
 struct NtMulti {
@@ -215,7 +289,7 @@ inline bool use_small_tiles(int M, int N) {
     static const int thr = [] {
         const char* e = getenv("XPS_GEMM_SMALL_TILE_BLOCKS");
         int v = e ? atoi(e) : -1;
-        return v >= 0 ? v : 1024;
+        return v >= 0 ? v : 2048;
     }();
     return M > 64 && (long long)cdiv(M, 128) * cdiv(N, BN) < thr;
 }
@@ -226,6 +300,11 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
     const int kchunk = ((K + BKT - 1) / BKT) * BKT + BKT;
     const int vecA = (int)(map_vec_ok(A, ra) && (!A2 || map_vec_ok(A2, ra)));
     const int vecB = (int)(map_vec_ok(B, rb) && (!B2 || map_vec_ok(B2, rb)));
+    if (M <= SM_MAXM) {
+        hipLaunchKernelGGL((gemm_small_kernel<AK, BK>), dim3(cdiv(N, 64)), dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc,
+                           bias, M, N, K, accumulate, vecB);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (use_small_tiles(M, N)) {
         dim3 grid(cdiv(N, BN) * cdiv(M, 64));
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,

@@ -79,8 +79,10 @@ __global__ __launch_bounds__(1024) void colsum_stage2(const float* __restrict__ 
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, double count, float* mean, float* rstd,
-                                   float* running_mean, float* running_var, float momentum, float eps, int F) {
+                                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                                   float momentum, float eps, int F) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= F) return;
     const double m = (double)stats[c] / count;
     double var = (double)stats[F + c] / count - m * m;
@@ -392,12 +394,12 @@ extern "C" int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, f
 }
 
 extern "C" int xps_bn_finalize_f32(const float* stats, double count, float* mean, float* rstd,
-                                   float* running_mean, float* running_var, float momentum, float eps,
-                                   int F, void* stream) {
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float momentum, float eps, int F, void* stream) {
     XPS_CHECK_ARG(stats && mean && rstd && F >= 1 && count >= 1, "bad argument");
     XPS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(F, 256)), dim3(256), 0, (hipStream_t)stream,
-                       stats, count, mean, rstd, running_mean, running_var, momentum, eps, F);
+                       stats, count, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, F);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

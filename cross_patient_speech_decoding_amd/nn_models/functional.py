@@ -137,6 +137,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, wc)
         ctx.params = (w, b)
         ctx.xshape = x.shape
+        ctx.x_param = x if isinstance(x, torch.nn.Parameter) and x.dim() == 2 else None    # e.g. an embedding table
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -148,9 +149,13 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(M, N).contiguous()
         dx = rw = rb = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=_f32, device=dy.device)
-            gemm_nn(dy2, wc, dx, M, K, N)
-            dx = dx.view(ctx.xshape)
+            gx, acc_x, _ = _grad_target(ctx.x_param, (M, K), dy.device) if ctx.x_param is not None else (None, False, None)
+            if acc_x:
+                gemm_nn(dy2, wc, gx, M, K, N, accumulate=True)
+            else:
+                dx = torch.empty(M, K, dtype=_f32, device=dy.device)
+                gemm_nn(dy2, wc, dx, M, K, N)
+                dx = dx.view(ctx.xshape)
         need_w, need_b = ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
             dw, acc_w, rw = _grad_target(w, (N, K), dy.device)
@@ -264,14 +269,19 @@ class GRURecurFn(torch.autograd.Function):
         return (dgi, dh0, None, *[r[0] for r in rets], *[r[1] for r in rets])
 
 
+HN_NONE, HN_STACK, HN_SUM = 0, 1, 2
+
+
 class GRULayerFn(torch.autograd.Function):
     """One (bi)directional GRU layer over a time-major input x (T, B, In):
     input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel + ONE grouped
     launch for all six weight/bias gradients.  weights: per direction (w_ih, w_hh, b_ih, b_hh).
-    Returns (y (T, B, ndir*H), hn (ndir, B, H))."""
+    Returns (y (T, B, ndir*H), hn).  hn_mode selects what hn is: HN_STACK (ndir, B, H) final state of each
+    direction; HN_SUM (B, H) their sum (what the seq2seq encoder hands to the decoder: one strided add, and
+    the backward gets ONE (B, H) gradient for both directions); HN_NONE: None (inner layers)."""
 
     @staticmethod
-    def forward(ctx, x, ndir, *wb):
+    def forward(ctx, x, ndir, hn_mode, *wb):
         ctx.set_materialize_grads(False)
         _need_gpu(x, *wb)
         x = x.contiguous()
@@ -290,17 +300,24 @@ class GRULayerFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
         ctx.params = wb
-        ctx.dims = (T, B, H, ndir, In)
+        ctx.dims = (T, B, H, ndir, In, hn_mode)
         # y: per-step outputs (a view of y_ext: slots 1..T); hn: final hidden state of each direction
         # (forward: t = T-1, reverse: t = 0), returned separately so that a consumer of the final state
-        # only (the seq2seq encoder) sends back a (ndir, B, H) gradient instead of a zero-padded (T, B, .) one
+        # only (the seq2seq encoder) sends back a small gradient instead of a zero-padded (T, B, .) one
         y = y_ext[1:T + 1]
-        hn = torch.stack([y_ext[T, :, :H]] + ([y_ext[1, :, H:]] if ndir == 2 else []), dim=0)
+        if hn_mode == HN_NONE:
+            hn = None
+        elif hn_mode == HN_SUM:
+            hn = y_ext[T, :, :H] + y_ext[1, :, H:] if ndir == 2 else y_ext[T, :, :H].clone()
+        else:
+            hn = torch.stack([y_ext[T, :, :H]] + ([y_ext[1, :, H:]] if ndir == 2 else []), dim=0)
         return y, hn
 
     @staticmethod
     def backward(ctx, dy, dhn):
-        T, B, H, ndir, In = ctx.dims
+        T, B, H, ndir, In, hn_mode = ctx.dims
+        if dhn is not None and hn_mode == HN_SUM:          # the same (B, H) gradient reaches both directions
+            dhn = dhn.unsqueeze(0).expand(ndir, B, H).contiguous()
         x, y_ext, saved, *w = ctx.saved_tensors
         w_ih, w_hh = w[:ndir], w[ndir:]
         wb = ctx.params
@@ -331,12 +348,19 @@ class GRULayerFn(torch.autograd.Function):
         grads = []
         for d in range(ndir):
             grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]
-        return (dx, None, *grads)
+        return (dx, None, None, *grads)
 
 
 # --------------------------------------------------------------------------- #
 # TemporalConv: Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                      #
 # --------------------------------------------------------------------------- #
+def _group_world(group):
+    import torch.distributed as dist
+    if group is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
 def _dist_sum_(t, group):
     import torch.distributed as dist
     if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -364,7 +388,7 @@ class TemporalConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, gamma, beta, running_mean, running_var, stride, training,
-                relu, drop_mask, drop_scale, momentum, eps, group, global_trials=None):
+                relu, drop_mask, drop_scale, momentum, eps, group, global_trials=None, num_batches_tracked=None):
         _need_gpu(x, conv_w)
         x = x.contiguous()
         B, T, Cin = x.shape
@@ -389,11 +413,12 @@ class TemporalConvFn(torch.autograd.Function):
             mean = torch.empty(F, dtype=_f32, device=x.device)
             rstd = torch.empty(F, dtype=_f32, device=x.device)
             call('xps_bn_finalize_f32', _ptr(stats), count, _ptr(mean), _ptr(rstd), _ptr(running_mean),
-                 _ptr(running_var), momentum, eps, F, _stream())
+                 _ptr(running_var), _ptr(num_batches_tracked), momentum, eps, F, _stream())
             call('xps_bn_apply_f32', _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(drop_mask),
                  drop_scale, _ptr(out), rows, F, int(relu), _stream())
             ctx.save_for_backward(x, w2, y, out, mean, rstd, gamma, drop_mask)
             ctx.cfg = (B, T, Cin, F, k, stride, Tp, relu, drop_scale, count, group)
+            ctx.conv_w = conv_w
         else:
             call('xps_bn_apply_eval_f32', _ptr(y), _ptr(running_mean), _ptr(running_var), eps, _ptr(gamma),
                  _ptr(beta), _ptr(out), rows, F, int(relu), _stream())
@@ -411,9 +436,12 @@ class TemporalConvFn(torch.autograd.Function):
         ws = _ws(nbytes, dev)
         call('xps_bn_bwd_reduce_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(drop_mask),
              drop_scale, int(relu), _ptr(sums), rows, F, _ptr(ws), nbytes, _stream())
-        dbeta = sums[:F].clone()
-        dgamma = sums[F:].clone()
-        _dist_sum_(sums, group)                 # SyncBN: the dy formula needs the global sums
+        if _group_world(group) > 1:             # SyncBN: the dy formula needs the global sums, the
+            local = sums.clone()                # parameter gradients the local ones (averaged with the rest later)
+            _dist_sum_(sums, group)
+        else:
+            local = sums
+        dbeta, dgamma = local[:F], local[F:]
         dy = torch.empty_like(y)
         call('xps_bn_bwd_apply_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
              _ptr(drop_mask), drop_scale, int(relu), _ptr(sums), count, _ptr(dy), rows, F, _stream())
@@ -423,8 +451,13 @@ class TemporalConvFn(torch.autograd.Function):
         dw2 = torch.empty(F, k * Cin, dtype=_f32, device=dev)
         gemm_tn_grouped([tn_problem(dy, x, dw2, F, k * Cin, rows, ra=rowmap(B * F, rpg=Tp, gs=F),
                                     rb=rowmap(stride * Cin, rpg=Tp, gs=T * Cin), colsum_out=dconv_b)], dev)
-        dconv_w = dw2.view(F, k, Cin).permute(0, 2, 1).contiguous()
-        return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 11
+        gw, acc_w, _ = _grad_target(ctx.conv_w, (F, Cin, k), dev)
+        if acc_w:                               # un-permute and accumulate in one pass, straight into .grad
+            gw.add_(dw2.view(F, k, Cin).permute(0, 2, 1))
+            dconv_w = None
+        else:
+            dconv_w = dw2.view(F, k, Cin).permute(0, 2, 1).contiguous()
+        return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 12
 
 
 # --------------------------------------------------------------------------- #
@@ -440,6 +473,7 @@ class DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, h0, w_hh, b_hh, w_fc, b_fc, teacher, flags, start_token, L):
+        ctx.set_materialize_grads(False)               # no zero tensor for the (integer) tokens output
         _need_gpu(table, h0, w_hh, w_fc)
         table, h0c = table.contiguous(), h0.contiguous()
         w_hh_c, b_hh_c, w_fc_c, b_fc_c = w_hh.contiguous(), b_hh.contiguous(), w_fc.contiguous(), b_fc.contiguous()
@@ -472,6 +506,8 @@ class DecoderFn(torch.autograd.Function):
         B, H, C, L, ntok = ctx.dims
         w_hh, b_hh, w_fc, b_fc = ctx.params
         dev = hs.device
+        if dlogits is None:
+            return (None,) * 10
         dlogits = dlogits.contiguous()
         w_t = transpose(w_hh_c, 3 * H, H)
         dgi = torch.empty(L, B, 3 * H, dtype=_f32, device=dev)

@@ -98,13 +98,14 @@ class TemporalConv(nn.Module):
         if training and p > 0:
             mask = XF.dropout_mask((Tp, B, F), p, x.device)
             scale = 1.0 / (1.0 - p)
-        if training and self.bn.track_running_stats:
-            self.bn.num_batches_tracked += 1
         momentum = 0.1 if self.bn.momentum is None else self.bn.momentum
+        # num_batches_tracked is bumped by the statistics kernel (no separate launch for one integer)
+        nbt = self.bn.num_batches_tracked if training and self.bn.track_running_stats else None
         return XF.TemporalConvFn.apply(x, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
                                        self.bn.running_mean, self.bn.running_var, s, training,
                                        bool(self.activation), mask, scale, momentum, self.bn.eps,
-                                       self.process_group, self.global_batch if self.process_group is not None else None)
+                                       self.process_group, self.global_batch if self.process_group is not None else None,
+                                       nbt)
 
     def forward(self, x):
         return self.forward_tm(x.permute(0, 2, 1)).permute(1, 2, 0)
@@ -141,12 +142,19 @@ class EncoderRNN(nn.Module):
         H, L = rnn.hidden_size, rnn.num_layers
         T = x.shape[0]
         y = x
+        y, last = self.forward_tm_last(x)
+        return y, last.unsqueeze(0)
+
+    def forward_tm_last(self, x):
+        """As forward_tm with the summed final state as a plain (B, H) tensor."""
+        rnn = self.rnn
+        L = rnn.num_layers
+        y = x
         for l in range(L):
-            y, hn = XF.GRULayerFn.apply(y, 2, *_gru_layer_weights(rnn, l, 2))
+            y, last = XF.GRULayerFn.apply(y, 2, XF.HN_SUM if l == L - 1 else XF.HN_NONE, *_gru_layer_weights(rnn, l, 2))
             if l < L - 1:
                 y = XF.dropout(y, rnn.dropout, self.training)
-        last = hn[0] + hn[1]                              # h_fwd(T-1) + h_bwd(0)
-        return y, last.unsqueeze(0)
+        return y, last                                    # last = h_fwd(T-1) + h_bwd(0)
 
     def forward(self, x):
         y, h = self.forward_tm(x.permute(1, 0, 2))
@@ -234,18 +242,18 @@ class Seq2SeqRNN(BaseLightningModel):
         """Sync-free forward: ``flags`` is a DEVICE int32 vector (seq_length,) of teacher-forcing
         decisions, so the whole step can be captured in a hipGraph."""
         z = self.temporal_conv.forward_tm(x)                       # (T', B, F)
-        _, enc_hidden = self.encoder.forward_tm(z)                  # (1, B, H)
+        _, enc_last = self.encoder.forward_tm_last(z)               # (B, H)
         rnn = self.decoder.rnn
         if (rnn.num_layers == 1 and self.num_classes + 1 <= 16
                 and XF.decoder_supported(rnn.hidden_size, self.num_classes, self.seq_length)):
             # fused path: every decode step in one launch, tokens chosen on the device
             table = self.decoder.token_projection()
-            logits, _ = XF.DecoderFn.apply(table, enc_hidden[0], rnn.weight_hh_l0, rnn.bias_hh_l0,
+            logits, _ = XF.DecoderFn.apply(table, enc_last, rnn.weight_hh_l0, rnn.bias_hh_l0,
                                            self.decoder.fc_out.weight, self.decoder.fc_out.bias,
                                            y if y is not None else None, flags if y is not None else None,
                                            self.num_classes, self.seq_length)
             return logits
-        dec_hidden = enc_hidden.repeat(self.decoder.rnn.num_layers, 1, 1)
+        dec_hidden = enc_last.unsqueeze(0).repeat(self.decoder.rnn.num_layers, 1, 1)
         B = x.size(0)
         tok = torch.full((B,), self.num_classes, dtype=torch.long, device=x.device)
         table = self.decoder.token_projection()

@@ -73,8 +73,8 @@ class FlatAdamW:
 
     @torch.no_grad()
     def step(self):
-        """all-reduce (mean) -> global grad norm -> fused clip + AdamW.  Returns the pre-clip norm
-        (device scalar, like clip_grad_norm_)."""
+        """all-reduce (mean) -> global grad norm -> fused clip + AdamW.  The pre-clip norm of the step
+        (what clip_grad_norm_ returns) is available from ``grad_norm()``."""
         world, _ = _world(self.group)
         # robustness: if someone reset .grad (model.zero_grad(set_to_none=True)) autograd allocated fresh
         # gradient tensors; fold them back into the flat buffer and restore the views
@@ -92,6 +92,9 @@ class FlatAdamW:
         XF.grad_sumsq(self.flat_g, out=self.sumsq)
         XF.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, self.max_norm or 0.0,
                       self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count)
+
+    def grad_norm(self):
+        """Global gradient norm (before clipping) of the last step: device scalar."""
         return self.sumsq.sqrt()[0]
 
     def state_dict(self):

@@ -145,9 +145,10 @@ int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* st
 /*   stats  : [2F] sum and sum of squares over rows (all-reduced by the caller    */
 /*            under data parallelism: SyncBN), count = global number of rows      */
 /* ------------------------------------------------------------------------- */
+/* num_batches_tracked: device int64 counter (BatchNorm1d buffer) incremented by one, or NULL */
 int xps_bn_finalize_f32(const float* stats, double count, float* mean, float* rstd,
-                        float* running_mean, float* running_var, float momentum, float eps,
-                        int F, void* stream);
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        float momentum, float eps, int F, void* stream);
 int xps_bn_apply_f32(const float* y, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* drop_mask, float drop_scale,
                      float* out, int64_t rows, int F, int relu, void* stream);

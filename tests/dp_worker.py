@@ -43,7 +43,8 @@ def hip_step(rank, world, X, y, group):
     logits = m(xs, ys, coins=[True, False, True])
     loss = m.criterion(logits.view(-1, 9), ys.view(-1)) * (xs.shape[0] * world / X.shape[0])
     loss.backward()
-    gnorm = opt.step()
+    opt.step()
+    gnorm = opt.grad_norm()
     return opt.flat_g.clone().cpu(), opt.flat_p.clone().cpu(), float(gnorm), m.temporal_conv.bn.running_var.cpu()
 
 

@@ -30,7 +30,8 @@ def dev(t):
 
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 9, 16), (37, 70, 100), (130, 129, 33), (300, 384, 256),
-                                   (257, 100, 640), (64, 27, 6)])
+                                   (257, 100, 640), (64, 27, 6), (10, 384, 128), (16, 130, 77), (13, 70, 1031),
+                                   (17, 64, 40)])
 def test_gemm_nt_nn_tn_exact_fp32(M, N, K):
     g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
     A = torch.randn(M, K, generator=g)
@@ -57,6 +58,31 @@ def test_gemm_nt_nn_tn_exact_fp32(M, N, K):
     out3 = torch.empty(M, N, device='cuda')
     xf.gemm_tn(dev(At), dev(Bk), out3, M, N, K)
     assert ((out3.cpu().double() - ref_nn).abs() <= 4e-7 * scale + 1e-30).all()
+
+
+@pytest.mark.parametrize('M,N,K1,K2', [(9, 100, 48, 48), (16, 65, 30, 7), (200, 100, 96, 96), (40, 33, 12, 50)])
+def test_gemm_nn2_two_operand_pairs(M, N, K1, K2):
+    """C = A1 B1 + A2 B2 in one launch (both directions of a bidirectional layer's input gradient)."""
+    import ctypes as C
+    from cross_patient_speech_decoding_amd._lib import call
+    g = torch.Generator().manual_seed(M + N + K1)
+    A1, B1 = torch.randn(M, K1, generator=g), torch.randn(K1, N, generator=g)
+    A2, B2 = torch.randn(M, K2, generator=g), torch.randn(K2, N, generator=g)
+    if K1 != K2:                      # the two pairs share row maps: pad the leading dimensions to a common one
+        ld = max(K1, K2)
+        A1p, A2p = torch.zeros(M, ld), torch.zeros(M, ld)
+        A1p[:, :K1], A2p[:, :K2] = A1, A2
+    else:
+        ld, A1p, A2p = K1, A1, A2
+    a1, b1, a2, b2 = dev(A1p), dev(B1), dev(A2p), dev(B2)
+    out = torch.full((M, N), 3.0, device='cuda')
+    ra, rb, rc = rowmap(ld), rowmap(N), rowmap(N)
+    call('xps_gemm_nn2_f32', a1.data_ptr(), b1.data_ptr(), K1, a2.data_ptr(), b2.data_ptr(), K2,
+         C.byref(ra), C.byref(rb), out.data_ptr(), C.byref(rc), M, N, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = A1.double() @ B1.double() + A2.double() @ B2.double() + 3.0
+    scale = A1.abs().double() @ B1.abs().double() + A2.abs().double() @ B2.abs().double() + 3.0
+    assert ((out.cpu().double() - ref).abs() <= 1e-6 * scale).all()
 
 
 def test_gemm_tn_long_k_split():
@@ -130,7 +156,7 @@ def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir):
     xf = XF()
     ws = [dev(w).requires_grad_(True) for w in _weights(gru, ndir)]
     xg = dev(x).requires_grad_(True)
-    y, hn = xf.GRULayerFn.apply(xg, ndir, *ws)
+    y, hn = xf.GRULayerFn.apply(xg, ndir, xf.HN_STACK, *ws)
     np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5)
     np.testing.assert_allclose(hn.detach().cpu().numpy(), hn_ref.detach().numpy(), atol=2e-5)
     (y * dev(wt)).sum().backward()
@@ -159,11 +185,35 @@ def test_gru_layer_final_state_gradient_only():
     xf = XF()
     ws = [dev(w).requires_grad_(True) for w in _weights(gru, 2)]
     xg = dev(x).requires_grad_(True)
-    _, hn = xf.GRULayerFn.apply(xg, 2, *ws)
+    _, hn = xf.GRULayerFn.apply(xg, 2, xf.HN_STACK, *ws)
     (hn * dev(wt)).sum().backward()
     np.testing.assert_allclose(xg.grad.cpu().numpy(), x_ref.grad.numpy(), atol=5e-5, rtol=1e-4)
     np.testing.assert_allclose(ws[1].grad.cpu().numpy(), gru.weight_hh_l0.grad.numpy(), atol=1e-4, rtol=1e-3)
     np.testing.assert_allclose(ws[4].grad.cpu().numpy(), gru.weight_ih_l0_reverse.grad.numpy(), atol=1e-4, rtol=1e-3)
+
+
+def test_gru_layer_summed_final_state():
+    """HN_SUM: h_fwd(T-1) + h_bwd(0) as one (B, H) tensor whose gradient reaches both directions."""
+    torch.set_num_threads(4)
+    T, B, In, H = 5, 21, 12, 64
+    gru = _cpu_gru(In, H, 2, seed=5)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(T, B, In, generator=g)
+    wt = torch.randn(B, H, generator=g)
+    x_ref = x.clone().requires_grad_(True)
+    _, hn_ref = gru(x_ref)
+    ((hn_ref[0] + hn_ref[1]) * wt).sum().backward()
+    xf = XF()
+    ws = [dev(w).requires_grad_(True) for w in _weights(gru, 2)]
+    xg = dev(x).requires_grad_(True)
+    y, last = xf.GRULayerFn.apply(xg, 2, xf.HN_SUM, *ws)
+    assert tuple(last.shape) == (B, H)
+    np.testing.assert_allclose(last.detach().cpu().numpy(), (hn_ref[0] + hn_ref[1]).detach().numpy(), atol=2e-5)
+    (last * dev(wt)).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x_ref.grad.numpy(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(ws[1].grad.cpu().numpy(), gru.weight_hh_l0.grad.numpy(), atol=1e-4, rtol=1e-3)
+    y2, none = xf.GRULayerFn.apply(xg, 2, xf.HN_NONE, *ws)
+    assert none is None and torch.equal(y2, y)
 
 
 def test_dropout_kernel_statistics_and_backward():

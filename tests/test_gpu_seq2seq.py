@@ -58,7 +58,8 @@ def test_train_step_matches_reference_golden(golden_dir, name, tag, coin):
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(g[f'{tag}_loss']), rtol=2e-5)
     assert np.abs(logits.detach().cpu().numpy() - g[f'{tag}_logits']).max() <= 1e-4
-    gnorm = opt.step()
+    opt.step()
+    gnorm = opt.grad_norm()
     np.testing.assert_allclose(float(gnorm), float(g[f'{tag}_gnorm']), rtol=2e-4)
     params = dict(m.named_parameters())
     if f'{tag}_grad/decoder.fc_out.weight' in g:
