@@ -47,76 +47,78 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
 }
 
 // Few-row products (M <= 16: the decoder's token table E W_ih^T and its input gradient).  An MFMA tile
-// would be > 87 % padding and, with one or two blocks, pure load latency; here a block owns 64 columns x
-// 4 k-slices, every lane keeps all M accumulators, A values are wave-uniform loads, and the four k-slices
-// are folded through LDS in a fixed order.
-constexpr int SM_MAXM = 16;
+// would be > 87 % padding and, with one or two blocks, pure load latency.  Here a 1024-thread block owns 64
+// columns x 16 k-slices (one wave each).  A (at most 16 x 1024 per chunk) is staged in LDS with coalesced
+// loads and read back as wave-uniform 16-byte broadcasts; every lane keeps all M accumulators; the sixteen
+// k-slices are folded through LDS in a fixed order.
+constexpr int SM_MAXM = 16, SM_SLICES = 16, SM_KC = 1024;
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void gemm_small_kernel(
+__global__ __launch_bounds__(1024) void gemm_small_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
     const float* __restrict__ A2, const float* __restrict__ B2, int K2,
     float* __restrict__ C, RowMap rc, const float* __restrict__ bias, int M, int N, int K, int accumulate, int vecB) {
-    __shared__ float red[4][SM_MAXM][64];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float As[SM_MAXM][SM_KC];
+    __shared__ float red[SM_SLICES][SM_MAXM][64];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int n = blockIdx.x * 64 + l;
     float acc[SM_MAXM];
 #pragma unroll
     for (int m = 0; m < SM_MAXM; ++m) acc[m] = 0.f;
-    long long aoff[SM_MAXM];
-#pragma unroll
-    for (int m = 0; m < SM_MAXM; ++m) aoff[m] = AK ? ra.off(m < M ? m : 0) : (long long)(m < M ? m : 0);
     for (int pass = 0; pass < 2; ++pass) {
-        const float* Ap = pass ? A2 : A;
-        const float* Bp = pass ? B2 : B;
+        const float* __restrict__ Ap = pass ? A2 : A;
+        const float* __restrict__ Bp = pass ? B2 : B;
         const int Kp = pass ? K2 : K;
         if (!Ap) break;
-        const int kq = (((Kp + 3) / 4) + 3) & ~3;               // k-slice length, multiple of 4
-        const int k0 = w * kq, k1 = min(Kp, k0 + kq);
-        if (n < N) {
-            const long long boff = BK ? rb.off(n) : (long long)n;
-            int k = k0;
-            if (BK && vecB) {
+        const bool plain_b = rb.rpg >= Kp;                       // k rows of B addressed by a plain leading dimension
+        for (int kc = 0; kc < Kp; kc += SM_KC) {
+            const int kn = min(SM_KC, Kp - kc);
+            __syncthreads();
+            for (int e = tid; e < SM_MAXM * kn; e += 1024) {     // stage A[0..M) x [kc, kc+kn); rows >= M are zero
+                const int m = e / kn, k = e - m * kn;
+                As[m][k] = m < M ? (AK ? Ap[ra.off(m) + kc + k] : Ap[ra.off(kc + k) + m]) : 0.f;
+            }
+            __syncthreads();
+            const int kq = (((kn + SM_SLICES - 1) / SM_SLICES) + 3) & ~3;       // k-slice length, multiple of 4
+            const int k0 = w * kq, k1 = min(kn, k0 + kq);
+            if (n < N) {
+                const long long boff = BK ? rb.off(n) + kc : (long long)n;
+                int k = k0;
                 for (; k + 3 < k1; k += 4) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(Bp + boff + k);
+                    float b[4];
+                    if (BK && vecB) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(Bp + boff + k);
+                        b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            b[j] = BK ? Bp[boff + k + j]
+                                      : Bp[(plain_b ? (long long)(kc + k + j) * rb.ld : rb.off(kc + k + j)) + boff];
+                    }
 #pragma unroll
                     for (int m = 0; m < SM_MAXM; ++m) {
-                        if (m < M) {
-                            if (AK) {
-                                const float* a = Ap + aoff[m] + k;
-                                acc[m] += a[0] * b.x; acc[m] += a[1] * b.y; acc[m] += a[2] * b.z; acc[m] += a[3] * b.w;
-                            } else {
-                                acc[m] += Ap[ra.off(k) + aoff[m]] * b.x; acc[m] += Ap[ra.off(k + 1) + aoff[m]] * b.y;
-                                acc[m] += Ap[ra.off(k + 2) + aoff[m]] * b.z; acc[m] += Ap[ra.off(k + 3) + aoff[m]] * b.w;
-                            }
-                        }
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(&As[m][k]);        // same address in every lane
+                        acc[m] += a.x * b[0]; acc[m] += a.y * b[1]; acc[m] += a.z * b[2]; acc[m] += a.w * b[3];
                     }
                 }
-            }
-            for (; k < k1; ++k) {
-                const float b = BK ? Bp[boff + k] : Bp[rb.off(k) + boff];
-                const long long ak = AK ? (long long)k : ra.off(k);
+                for (; k < k1; ++k) {
+                    const float b = BK ? Bp[boff + k] : Bp[(plain_b ? (long long)(kc + k) * rb.ld : rb.off(kc + k)) + boff];
 #pragma unroll
-                for (int m = 0; m < SM_MAXM; ++m)
-                    if (m < M) acc[m] += Ap[AK ? aoff[m] + ak : ak + aoff[m]] * b;
+                    for (int m = 0; m < SM_MAXM; ++m) acc[m] += As[m][k] * b;
+                }
             }
         }
     }
 #pragma unroll
     for (int m = 0; m < SM_MAXM; ++m) red[w][m][l] = acc[m];
     __syncthreads();
-    // 256 threads fold 16 x 64 outputs: thread -> (rows w, w+4, w+8, w+12; column l)
-    if (n < N) {
+    if (w < M && n < N) {                        // wave w folds output row w
+        float v = 0.f;
 #pragma unroll
-        for (int mm = 0; mm < SM_MAXM / 4; ++mm) {
-            const int m = w + 4 * mm;
-            if (m < M) {
-                float v = (red[0][m][l] + red[1][m][l]) + (red[2][m][l] + red[3][m][l]);
-                if (bias) v += bias[n];
-                float* c = C + rc.off(m) + n;
-                if (accumulate) v += *c;
-                *c = v;
-            }
-        }
+        for (int s = 0; s < SM_SLICES; ++s) v += red[s][w][l];
+        if (bias) v += bias[n];
+        float* c = C + rc.off(w) + n;
+        if (accumulate) v += *c;
+        *c = v;
     }
 }
 
@@ -301,7 +303,7 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
     const int vecA = (int)(map_vec_ok(A, ra) && (!A2 || map_vec_ok(A2, ra)));
     const int vecB = (int)(map_vec_ok(B, rb) && (!B2 || map_vec_ok(B2, rb)));
     if (M <= SM_MAXM) {
-        hipLaunchKernelGGL((gemm_small_kernel<AK, BK>), dim3(cdiv(N, 64)), dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc,
+        hipLaunchKernelGGL((gemm_small_kernel<AK, BK>), dim3(cdiv(N, 64)), dim3(1024), 0, st, A, ra, B, rb, A2, B2, K2, C, rc,
                            bias, M, N, K, accumulate, vecB);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
