@@ -179,10 +179,10 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const long l
 }
 
 // scatter-add of batch rows into a small table, deterministic, two stages:
-// stage 1: block (strip of 64 columns, chunk of 64 batch rows) accumulates into an LDS copy of the
+// stage 1: block (strip of 64 columns, chunk of SC_CHUNK batch rows) accumulates into an LDS copy of the
 //          table (each thread owns one (row-group, column): no atomics) and writes its partial table;
 // stage 2: partial tables are summed in chunk order.
-constexpr int SC_CHUNK = 256, SC_MAXROWS = 16;
+constexpr int SC_CHUNK = 64, SC_MAXROWS = 16;
 __global__ __launch_bounds__(256) void scatter_rows_stage1(const float* __restrict__ dout, const long long* __restrict__ idx,
                                                            float* __restrict__ part, int B, int cols, int n_rows) {
     __shared__ float tab[4][SC_MAXROWS][64];
@@ -202,13 +202,30 @@ __global__ __launch_bounds__(256) void scatter_rows_stage1(const float* __restri
         for (int r = q; r < n_rows; r += 4)
             part[((long long)blockIdx.y * n_rows + r) * cols + c] = (tab[0][r][l] + tab[1][r][l]) + (tab[2][r][l] + tab[3][r][l]);
 }
-__global__ void scatter_rows_stage2(const float* __restrict__ part, int nchunks, float* __restrict__ dtable,
-                                    long long total, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// one block = 64 table entries x 4 chunk lanes (a wave each, 8 loads in flight); fixed fold order
+__global__ __launch_bounds__(256) void scatter_rows_stage2(const float* __restrict__ part, int nchunks, float* __restrict__ dtable,
+                                                           long long total, int accumulate) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + l;
     float a = 0.f;
-    for (int k = 0; k < nchunks; ++k) a += part[(long long)k * total + i];
-    dtable[i] = accumulate ? dtable[i] + a : a;
+    if (i < total) {
+        int k = w;
+        for (; k + 28 < nchunks; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + 4 * u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; k < nchunks; k += 4) a += part[(long long)k * total + i];
+    }
+    red[w][l] = a;
+    __syncthreads();
+    if (w == 0 && i < total) {
+        a = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        dtable[i] = accumulate ? dtable[i] + a : a;
+    }
 }
 
 __global__ void next_token_kernel(const float* __restrict__ logits, int C, const long long* __restrict__ teacher,
@@ -500,7 +517,7 @@ extern "C" int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float
         XPS_CHECK_LAUNCH();
     }
     const long long total = (long long)n_rows * cols;
-    hipLaunchKernelGGL(scatter_rows_stage2, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_rows_stage2, dim3(cdiv(total, 64)), dim3(256), 0, (hipStream_t)stream,
                        part, nchunks, dtable, total, accumulate);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
