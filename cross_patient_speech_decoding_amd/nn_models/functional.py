@@ -7,6 +7,7 @@ fallback: a non-CUDA tensor raises.
 Internal activation layout is TIME-MAJOR: (T, B, features).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -88,6 +89,44 @@ def gemm_tn_grouped(problems, device):
         nbytes = lib().xps_gemm_tn_grouped_f32_workspace(arr, len(chunk))
         ws = _ws(nbytes, device)
         call('xps_gemm_tn_grouped_f32', arr, len(chunk), _ptr(ws), nbytes, _stream())
+
+
+# Weight-gradient GEMMs are off the critical path of the backward pass (nothing downstream reads them until
+# the optimiser step), while the recurrence kernels that ARE on it leave ~40 % of the MFMA pipe idle and the
+# element-wise kernels all of it.  They are therefore launched on a second HIP stream and co-scheduled with
+# whatever the main stream runs next; the main stream re-joins when the autograd engine finishes the pass.
+# Only done when the results land straight in .grad buffers (DIRECT_GRAD): nothing on the main stream may
+# consume them before the join.  Deterministic: stream order does not change any reduction order.
+OVERLAP_WEIGHT_GRADS = os.environ.get('XPS_OVERLAP_WGRAD', '1') != '0'
+_side_streams = {}
+_side_pending = set()
+
+
+def _join_side_streams():
+    for dev_index in list(_side_pending):
+        torch.cuda.current_stream(dev_index).wait_stream(_side_streams[dev_index])
+    _side_pending.clear()
+
+
+def _launch_weight_grads(fn, device, tensors, direct):
+    """fn() enqueues weight-gradient kernels reading `tensors`.  Runs it on the side stream when allowed."""
+    if not (OVERLAP_WEIGHT_GRADS and direct):
+        fn()
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _side_streams.get(idx)
+    if side is None:
+        side = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    side.wait_stream(torch.cuda.current_stream(idx))
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    if idx not in _side_pending:
+        if not _side_pending:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+        _side_pending.add(idx)
 
 
 # When a parameter already owns a contiguous .grad buffer (FlatAdamW points every .grad into ONE flat
@@ -344,7 +383,8 @@ class GRULayerFn(torch.autograd.Function):
                 rw, rb = dw, db
             probs.append(tn_problem(dgi[d], x, dw, 3 * H, In, T * B, colsum_out=db, accumulate=acc_w))
             rets_ih.append((rw, rb))
-        gemm_tn_grouped(probs, dev)
+        direct = all(r[0] is None and r[1] is None for r in rets_ih + rets_hh)
+        _launch_weight_grads(lambda: gemm_tn_grouped(probs, dev), dev, (dgi, dghn, x, y_ext), direct)
         grads = []
         for d in range(ndir):
             grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]
