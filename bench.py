@@ -102,7 +102,7 @@ def _event_time(fn, iters=20, warm=3):
 
 
 def time_dominant_kernel(model, c):
-    """Roofline of the kernel with the largest share of the step (profiles/round1/r1b_*): the fp32-MFMA
+    """Roofline of the kernel with the largest share of the step (profiles/round1/r1c_*): the fp32-MFMA
     GEMM tile kernel, measured on its largest single launch = the grouped weight-gradient GEMM of encoder
     layer 1 (6 problems, K = T'*B rows).  Algorithmic FLOPs = sum 2*M*N*K over the group.  The fused GRU
     recurrence (second largest) is reported beside it."""
