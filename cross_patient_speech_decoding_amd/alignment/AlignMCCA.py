@@ -88,18 +88,25 @@ def _gevp(G, offs, n_components, regs):
     D = G.shape[0]
     LHS = G.copy()
     S = np.zeros_like(G)
+    blocks = []
     for b in range(P):
         sl = slice(offs[b], offs[b + 1])
         Rb = G[sl, sl] if regs is None else (1.0 - regs) * G[sl, sl] + regs * np.eye(offs[b + 1] - offs[b])
         LHS[sl, sl] = Rb
-        w, V = LA.eigh_psd(LA.to_device(Rb))
-        keep = w > w[0] * max(Rb.shape[0], 1) * LA.EPS          # guards a singular unregularised block
+        blocks.append(Rb)
+    # all diagonal blocks in one launch when they have one size
+    eigs = LA.eigh_psd_batched(blocks)
+    for b, (w, V) in enumerate(eigs):
+        sl = slice(offs[b], offs[b + 1])
+        keep = w > w[0] * max(blocks[b].shape[0], 1) * LA.EPS   # guards a singular unregularised block
         Vk = V[:, keep] / np.sqrt(w[keep])
         S[sl, sl] = LA.dgemm(LA.to_device(Vk), LA.to_device(V[:, keep]), tb=True).cpu().numpy()   # R_b^-1/2
     Sd = LA.to_device(S)
     Cm = LA.dgemm(LA.dgemm(Sd, LA.to_device(LHS)), Sd)
     Cm = 0.5 * (Cm + Cm.t())
     k = min(n_components, D)
+    # Cm = S G S + blockdiag(I - R_b^-1/2 G_bb R_b^-1/2) is indefinite once regs > 0 (eigenvalues down to
+    # -regs / (1 - regs)): eigh_sym_top shifts it positive definite before the (sign-blind) one-sided Jacobi
     w, Vc = LA.eigh_sym_top(Cm, k)
     Vg = LA.dgemm(Sd, LA.to_device(np.ascontiguousarray(Vc))).cpu().numpy()      # RHS-orthonormal
     return [Vg[offs[b]:offs[b + 1]] for b in range(P)], w

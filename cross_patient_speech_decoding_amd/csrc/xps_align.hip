@@ -186,59 +186,212 @@ __device__ inline void rr_pair(int ne, int r, int i, int& p, int& q) {
     if (p > q) { int t = p; p = q; q = t; }
 }
 
+// Rotation angle of one column pair from (alpha, beta, gamma) = (|p|^2, |q|^2, p.q); rel = |cos angle|.
+__device__ inline void jacobi_angle(double alpha, double beta, double gamma, double& c, double& s, double& rel) {
+    c = 1.0; s = 0.0;
+    const double denom = sqrt(alpha * beta);
+    rel = denom > 0.0 ? fabs(gamma) / denom : 0.0;
+    if (rel > 1e-15 && fabs(gamma) > 0.0) {
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        c = 1.0 / sqrt(1.0 + t * t);
+        s = c * t;
+    }
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One launch per round; block b owns pair (p, q).  EPT > 0: both columns (m <= 256*EPT) stay in registers
+// between the dot products and the rotation (one pass over W instead of two); EPT == 0: any m, two passes.
+// V == nullptr: the caller does not need the accumulated rotations (eigenvectors of a positive-definite
+// matrix are the normalised columns of W) -> half the traffic.
+template <int EPT>
 __global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ W, long long ldw, double* __restrict__ V,
                                                            long long ldv, int m, int n, int ne, int round,
                                                            unsigned long long* __restrict__ off_bits) {
-    __shared__ double sa[256], sb[256], sg[256];
-    __shared__ double cs[2];
+    __shared__ double red[3][4];
     int p, q;
     rr_pair(ne, round, blockIdx.x, p, q);
     if (q >= n) return;                      // padded (odd n) partner
     double* wp = W + (long long)p * ldw;
     double* wq = W + (long long)q * ldw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double x[EPT > 0 ? EPT : 1], y[EPT > 0 ? EPT : 1];
     double a = 0.0, b = 0.0, g = 0.0;
-    for (int i = threadIdx.x; i < m; i += 256) {
-        const double x = wp[i], y = wq[i];
-        a += x * x; b += y * y; g += x * y;
-    }
-    sa[threadIdx.x] = a; sb[threadIdx.x] = b; sg[threadIdx.x] = g;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sa[threadIdx.x] += sa[threadIdx.x + s];
-            sb[threadIdx.x] += sb[threadIdx.x + s];
-            sg[threadIdx.x] += sg[threadIdx.x + s];
+    if (EPT > 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + 256 * e;
+            x[e] = i < m ? wp[i] : 0.0;
+            y[e] = i < m ? wq[i] : 0.0;
         }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double alpha = sa[0], beta = sb[0], gamma = sg[0];
-        double c = 1.0, s = 0.0;
-        const double denom = sqrt(alpha * beta);
-        const double rel = denom > 0.0 ? fabs(gamma) / denom : 0.0;
-        if (rel > 1e-15 && fabs(gamma) > 0.0) {
-            const double zeta = (beta - alpha) / (2.0 * gamma);
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            c = 1.0 / sqrt(1.0 + t * t);
-            s = c * t;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { a += x[e] * x[e]; b += y[e] * y[e]; g += x[e] * y[e]; }
+    } else {
+        for (int i = tid; i < m; i += 256) {
+            const double xv = wp[i], yv = wq[i];
+            a += xv * xv; b += yv * yv; g += xv * yv;
         }
-        cs[0] = c; cs[1] = s;
-        if (off_bits) atomicMax(off_bits, (unsigned long long)__double_as_longlong(rel));
     }
+    a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = g; }
     __syncthreads();
-    const double c = cs[0], s = cs[1];
+    const double alpha = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double beta = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double gamma = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    double c, s, rel;
+    jacobi_angle(alpha, beta, gamma, c, s, rel);
+    if (tid == 0 && off_bits) atomicMax(off_bits, (unsigned long long)__double_as_longlong(rel));
     if (s == 0.0) return;
-    for (int i = threadIdx.x; i < m; i += 256) {
-        const double x = wp[i], y = wq[i];
-        wp[i] = c * x - s * y;
-        wq[i] = s * x + c * y;
+    if (EPT > 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + 256 * e;
+            if (i < m) {
+                wp[i] = c * x[e] - s * y[e];
+                wq[i] = s * x[e] + c * y[e];
+            }
+        }
+    } else {
+        for (int i = tid; i < m; i += 256) {
+            const double xv = wp[i], yv = wq[i];
+            wp[i] = c * xv - s * yv;
+            wq[i] = s * xv + c * yv;
+        }
     }
-    double* vp = V + (long long)p * ldv;
-    double* vq = V + (long long)q * ldv;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double x = vp[i], y = vq[i];
-        vp[i] = c * x - s * y;
-        vq[i] = s * x + c * y;
+    if (V) {
+        double* vp = V + (long long)p * ldv;
+        double* vq = V + (long long)q * ldv;
+        for (int i = tid; i < n; i += 256) {
+            const double xv = vp[i], yv = vq[i];
+            vp[i] = c * xv - s * yv;
+            vq[i] = s * xv + c * yv;
+        }
+    }
+}
+
+// Whole decomposition of a SMALL matrix (n <= 128 columns) in ONE launch: one workgroup per matrix of the
+// batch, W (and V when it fits) live in LDS, 8 lanes per column pair, all sweeps and the convergence test run
+// inside the kernel (the per-round launch version spends ~6 us per round: 6 ms for a 128 x 128 eigenproblem).
+// LDS columns are padded to an odd length so that the 8 pairs of a wave fall on different banks.
+// V mode: 0 = no V, 1 = V in LDS, 2 = V in global memory (n x n does not fit beside W).
+constexpr int JS_THREADS = 512, JS_LPP = 8, JS_MAX_N = 2 * (JS_THREADS / JS_LPP), JS_LDS_DOUBLES = 19200;
+constexpr int JS_EPL = JS_MAX_N / JS_LPP;          // elements of a column per lane (m, n <= JS_MAX_N)
+__global__ __launch_bounds__(JS_THREADS) void jacobi_small_kernel(double* __restrict__ Wg, long long ldw, long long sw,
+                                                                  double* __restrict__ Vg, long long ldv, long long sv,
+                                                                  int m, int n, int vmode, int max_sweeps, double tol,
+                                                                  int* __restrict__ sweeps_done, double* __restrict__ off_out) {
+    extern __shared__ double jlds[];
+    __shared__ double s_off[JS_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int ldW = m | 1, ldVs = n | 1;
+    double* W = jlds;
+    Wg += (long long)blockIdx.x * sw;
+    if (Vg) Vg += (long long)blockIdx.x * sv;
+    double* V = vmode == 1 ? jlds + (size_t)n * ldW : Vg;
+    const long long ldV = vmode == 1 ? (long long)ldVs : ldv;
+    for (int idx = tid; idx < n * m; idx += JS_THREADS) {
+        const int col = idx / m, i = idx - col * m;
+        W[col * ldW + i] = Wg[(long long)col * ldw + i];
+    }
+    if (vmode)
+        for (int idx = tid; idx < n * n; idx += JS_THREADS) {
+            const int col = idx / n, i = idx - col * n;
+            V[col * ldV + i] = col == i ? 1.0 : 0.0;
+        }
+    __syncthreads();
+    const int ne = (n + 1) & ~1, pairs = ne / 2;
+    const int t = tid & (JS_LPP - 1), pj = tid / JS_LPP;
+    int sweep = 0;
+    double last_off = 0.0;
+    while (sweep < max_sweeps) {
+        double offmax = 0.0;
+        for (int r = 0; r < ne - 1; ++r) {
+            if (pj < pairs) {
+                int p, q;
+                rr_pair(ne, r, pj, p, q);
+                if (q < n) {
+                    double* wp = W + p * ldW;
+                    double* wq = W + q * ldW;
+                    // both columns in registers (<= 16 elements per lane): one LDS read per element and no
+                    // read-after-write stalls between the dot products and the rotation
+                    double x[JS_EPL], y[JS_EPL];
+                    double a = 0.0, b = 0.0, g = 0.0;
+#pragma unroll
+                    for (int e = 0; e < JS_EPL; ++e) {
+                        const int i = t + JS_LPP * e;
+                        x[e] = i < m ? wp[i] : 0.0;
+                        y[e] = i < m ? wq[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int e = 0; e < JS_EPL; ++e) { a += x[e] * x[e]; b += y[e] * y[e]; g += x[e] * y[e]; }
+#pragma unroll
+                    for (int o = JS_LPP / 2; o > 0; o >>= 1) {
+                        a += __shfl_xor(a, o, JS_LPP); b += __shfl_xor(b, o, JS_LPP); g += __shfl_xor(g, o, JS_LPP);
+                    }
+                    double c, s, rel;
+                    jacobi_angle(a, b, g, c, s, rel);
+                    offmax = fmax(offmax, rel);
+                    if (s != 0.0) {
+#pragma unroll
+                        for (int e = 0; e < JS_EPL; ++e) {
+                            const int i = t + JS_LPP * e;
+                            if (i < m) {
+                                wp[i] = c * x[e] - s * y[e];
+                                wq[i] = s * x[e] + c * y[e];
+                            }
+                        }
+                        if (vmode) {
+                            double* vp = V + p * ldV;
+                            double* vq = V + q * ldV;
+#pragma unroll
+                            for (int e = 0; e < JS_EPL; ++e) {           // all loads in flight before the first store
+                                const int i = t + JS_LPP * e;
+                                x[e] = i < n ? vp[i] : 0.0;
+                                y[e] = i < n ? vq[i] : 0.0;
+                            }
+#pragma unroll
+                            for (int e = 0; e < JS_EPL; ++e) {
+                                const int i = t + JS_LPP * e;
+                                if (i < n) {
+                                    vp[i] = c * x[e] - s * y[e];
+                                    vq[i] = s * x[e] + c * y[e];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        ++sweep;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) offmax = fmax(offmax, __shfl_xor(offmax, o, 64));
+        if ((tid & 63) == 0) s_off[tid >> 6] = offmax;
+        __syncthreads();
+        double mx = 0.0;
+#pragma unroll
+        for (int w = 0; w < JS_THREADS / 64; ++w) mx = fmax(mx, s_off[w]);
+        last_off = mx;
+        __syncthreads();
+        if (mx <= tol) break;                   // block-uniform
+    }
+    for (int idx = tid; idx < n * m; idx += JS_THREADS) {
+        const int col = idx / m, i = idx - col * m;
+        Wg[(long long)col * ldw + i] = W[col * ldW + i];
+    }
+    if (vmode == 1)
+        for (int idx = tid; idx < n * n; idx += JS_THREADS) {
+            const int col = idx / n, i = idx - col * n;
+            Vg[(long long)col * ldv + i] = V[col * ldV + i];
+        }
+    if (tid == 0) {
+        if (sweeps_done) sweeps_done[blockIdx.x] = sweep;
+        if (off_out) off_out[blockIdx.x] = last_off;
     }
 }
 
@@ -361,11 +514,62 @@ extern "C" int xps_dgemm_small(const double* A, int64_t lda, int ta, const doubl
 
 extern "C" size_t xps_jacobi_f64_workspace(int n) { (void)n; return 16; }
 
+namespace {
+void launch_jacobi_round(double* W, long long ldw, double* V, long long ldv, int m, int n, int ne, int r,
+                         unsigned long long* off, hipStream_t st) {
+    if (m <= 1024)
+        hipLaunchKernelGGL(jacobi_round_kernel<4>, dim3(ne / 2), dim3(256), 0, st, W, ldw, V, ldv, m, n, ne, r, off);
+    else if (m <= 2048)
+        hipLaunchKernelGGL(jacobi_round_kernel<8>, dim3(ne / 2), dim3(256), 0, st, W, ldw, V, ldv, m, n, ne, r, off);
+    else
+        hipLaunchKernelGGL(jacobi_round_kernel<0>, dim3(ne / 2), dim3(256), 0, st, W, ldw, V, ldv, m, n, ne, r, off);
+}
+
+// 0 = not supported, else the V mode the small kernel would use
+int jacobi_small_vmode(int m, int n, int want_v) {
+    if (m < 1 || n < 1 || n > JS_MAX_N || m > JS_MAX_N) return -1;
+    const long long w = (long long)n * (m | 1);
+    if (w > JS_LDS_DOUBLES) return -1;
+    if (!want_v) return 0;
+    return (w + (long long)n * (n | 1) <= JS_LDS_DOUBLES) ? 1 : 2;
+}
+}  // namespace
+
+extern "C" int xps_jacobi_small_supported(int m, int n, int want_v) { return jacobi_small_vmode(m, n, want_v) >= 0; }
+
+extern "C" int xps_jacobi_small_f64(double* W, int64_t ldw, int64_t stride_w, double* V, int64_t ldv, int64_t stride_v,
+                                    int m, int n, int batch, int max_sweeps, double tol, int32_t* sweeps_done,
+                                    double* off, void* stream) {
+    XPS_CHECK_ARG(W && m >= 1 && n >= 1 && batch >= 0 && max_sweeps >= 0, "bad argument");
+    XPS_CHECK_ARG(ldw >= m && (!V || ldv >= n), "leading dimensions too small (column-major)");
+    if (batch == 0) return XPS_OK;
+    const int vmode = jacobi_small_vmode(m, n, V != nullptr);
+    if (vmode < 0) {
+        xps_set_error("xps_jacobi_small_f64: %d x %d does not fit the single-workgroup kernel", m, n);
+        return XPS_E_INVALID;
+    }
+    const size_t lds = ((size_t)n * (m | 1) + (vmode == 1 ? (size_t)n * (n | 1) : 0)) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                JS_LDS_DOUBLES * (int)sizeof(double)) != hipSuccess) {
+            xps_set_error("xps_jacobi_small_f64: cannot raise the dynamic LDS limit");
+            return XPS_E_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jacobi_small_kernel, dim3(batch), dim3(JS_THREADS), lds, (hipStream_t)stream, W, (long long)ldw,
+                       (long long)stride_w, V, (long long)ldv, (long long)stride_v, m, n, vmode, max_sweeps, tol,
+                       (int*)sweeps_done, off);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
 extern "C" int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t ldv, int m, int n, int sweeps,
                                      double* off, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
-    XPS_CHECK_ARG(W && V && m >= 1 && n >= 1 && sweeps >= 0, "bad argument");
-    XPS_CHECK_ARG(ldw >= m && ldv >= n, "leading dimensions too small (column-major)");
+    XPS_CHECK_ARG(W && m >= 1 && n >= 1 && sweeps >= 0, "bad argument");
+    XPS_CHECK_ARG(ldw >= m && (!V || ldv >= n), "leading dimensions too small (column-major)");
     hipStream_t st = (hipStream_t)stream;
     const int ne = (n + 1) & ~1;
     if (n == 1 || sweeps == 0) {
@@ -381,8 +585,8 @@ extern "C" int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t 
             }
         }
         for (int r = 0; r < ne - 1; ++r) {
-            hipLaunchKernelGGL(jacobi_round_kernel, dim3(ne / 2), dim3(256), 0, st, W, (long long)ldw, V,
-                               (long long)ldv, m, n, ne, r, (last && off) ? (unsigned long long*)off : nullptr);
+            launch_jacobi_round(W, (long long)ldw, V, (long long)ldv, m, n, ne, r,
+                                (last && off) ? (unsigned long long*)off : nullptr, st);
         }
         XPS_CHECK_LAUNCH();
     }

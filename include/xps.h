@@ -272,9 +272,19 @@ int xps_xcov_f64(const void* A, int a_is_f32, int64_t lda, const double* mean_a,
  * singular vectors.  For a symmetric PSD matrix this is its eigendecomposition.
  * `sweeps` full sweeps are enqueued (no host sync); off[0] receives the largest
  * |cos angle| seen in the last sweep.                                          */
+/* V may be NULL (rotations not accumulated: for a positive-definite matrix the eigenvectors are the normalised
+ * columns of W).                                                                */
 size_t xps_jacobi_f64_workspace(int n);
 int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t ldv, int m, int n, int sweeps,
                           double* off, void* workspace, size_t workspace_bytes, void* stream);
+/* Small problems (n <= 128 columns, n*m doubles within one workgroup's LDS): the WHOLE decomposition of each of
+ * `batch` matrices (stride_w / stride_v doubles apart) in one launch, one workgroup per matrix; sweeps run
+ * until the largest |cos angle| of a sweep is <= tol or max_sweeps.  V (optional) is SET to the accumulated
+ * rotations (identity on entry is implied).  sweeps_done[batch], off[batch]: optional device outputs.       */
+int xps_jacobi_small_supported(int m, int n, int want_v);
+int xps_jacobi_small_f64(double* W, int64_t ldw, int64_t stride_w, double* V, int64_t ldv, int64_t stride_v,
+                         int m, int n, int batch, int max_sweeps, double tol, int32_t* sweeps_done, double* off,
+                         void* stream);
 /* Y[r][:] = (X[r][:] - mean) @ Wt   X: n x d_in (float32 or float64), W: d_in x d_out float64,
  * Y float64 or float32.  Batched transform apply of every aligner.              */
 int xps_apply_f64(const void* X, int x_is_f32, int64_t ldx, const double* mean, const double* W,

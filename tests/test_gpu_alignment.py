@@ -284,3 +284,36 @@ def test_jacobi_eigh_d1024_and_svd():
     np.testing.assert_allclose(s, np.linalg.svd(M, compute_uv=False), rtol=1e-12)
     np.testing.assert_allclose((U * s) @ Vt, M, atol=1e-12)
     np.testing.assert_allclose(la.pinv_small(M), np.linalg.pinv(M), atol=1e-12)
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 31, 96, 97, 128])
+def test_jacobi_single_workgroup_kernel(n):
+    """The one-launch Jacobi (W, and V when it fits, in LDS): eigenpairs of PSD matrices incl. rank-deficient
+    ones (V in LDS for n <= 96, V in global memory above), odd sizes, and the batched entry point."""
+    la = LA()
+    rng = np.random.default_rng(n)
+    Bm = rng.standard_normal((n, max(n // 2, 1)))             # rank n/2: the null space needs accumulated V
+    C = Bm @ Bm.T
+    w, V = la.eigh_psd(torch.from_numpy(C).cuda())
+    wr = np.linalg.eigvalsh(C)[::-1]
+    np.testing.assert_allclose(w, wr, atol=1e-10 * max(wr[0], 1e-300))
+    np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-12)
+    np.testing.assert_allclose(V.T @ C @ V, np.diag(w), atol=1e-10 * max(wr[0], 1e-300))
+    # well-conditioned shortcut (no accumulated rotations) and the batch of 5 matrices in one launch
+    Cs = [Bm @ Bm.T * (1 + i) + 0.5 * np.eye(n) for i in range(5)]
+    for (w, V), Ci in zip(la.eigh_psd_batched(Cs, well_conditioned=True), Cs):
+        np.testing.assert_allclose(w, np.linalg.eigvalsh(Ci)[::-1], rtol=1e-11)
+        np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-11)
+        np.testing.assert_allclose(V.T @ Ci @ V, np.diag(w), atol=1e-10 * w[0])
+
+
+def test_eigh_sym_top_indefinite_matrix():
+    la = LA()
+    rng = np.random.default_rng(3)
+    for n, k in ((200, 30), (64, 5)):
+        A = rng.standard_normal((n, n))
+        C = A + A.T                                            # indefinite
+        w, V = la.eigh_sym_top(torch.from_numpy(C).cuda(), k)
+        wr, Vr = np.linalg.eigh(C)
+        np.testing.assert_allclose(w, wr[::-1][:k], atol=1e-10 * np.abs(wr).max())
+        assert np.abs(C @ V - V * w).max() <= 1e-10 * np.abs(wr).max()
