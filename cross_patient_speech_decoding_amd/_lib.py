@@ -72,6 +72,8 @@ SIGNATURES = {
     'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'xps_cross_entropy_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     'xps_cross_entropy_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    'xps_ctc_loss_f32_workspace': (_sz, [_i, _i, _i]),
+    'xps_ctc_loss_f32': (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xps_sumsq_f32_workspace': (_sz, [_i64]),
     'xps_sumsq_f32': (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
     'xps_adamw_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),

@@ -722,6 +722,92 @@ def cross_entropy(logits, target):
     return CrossEntropyFn.apply(logits, target)
 
 
+class CTCLossFn(torch.autograd.Function):
+    """nn.CTCLoss(blank, reduction='mean', zero_infinity) on TIME-major raw scores (T, B, C): log-softmax, alpha,
+    beta and the gradient with respect to the scores in one launch (xps_ctc_loss_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank, zero_infinity):
+        _need_gpu(logits)
+        if targets.dim() != 2:
+            raise ValueError('targets must be a padded (batch, max_target_length) tensor')
+        logits = logits.contiguous()
+        T, B, Cn = logits.shape
+        dev = logits.device
+        if not input_lengths.is_cuda and int(input_lengths.max()) > T:         # torch's own check (host lengths only)
+            raise RuntimeError(f'Expected input_lengths to have value at most {T}, but got value '
+                               f'{int(input_lengths.max())}')
+        tg = targets.to(device=dev, dtype=torch.int64).contiguous()
+        il = input_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        tl = target_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        Lmax = tg.shape[1]
+        nll = torch.empty(B, dtype=_f32, device=dev)
+        loss = torch.empty(1, dtype=_f32, device=dev)
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty_like(logits) if need else None
+        nbytes = lib().xps_ctc_loss_f32_workspace(T, B, Lmax)
+        ws = _ws(nbytes, dev)
+        call('xps_ctc_loss_f32', _ptr(logits), _ptr(tg), tg.stride(0), _ptr(il), _ptr(tl), T, B, Cn, Lmax, int(blank),
+             int(bool(zero_infinity)), _ptr(nll), _ptr(loss), _ptr(dl), _ptr(ws), nbytes, _stream())
+        if need:
+            ctx.save_for_backward(dl)
+        ctx.nll = nll
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dl,) = ctx.saved_tensors
+        return dl * gout, None, None, None, None, None
+
+
+def ctc_loss(logits_tm, targets, input_lengths, target_lengths, blank=0, zero_infinity=True):
+    return CTCLossFn.apply(logits_tm, targets, input_lengths, target_lengths, blank, zero_infinity)
+
+
+class WindowLinearFn(torch.autograd.Function):
+    """Input projection of right-aligned sliding windows without materialising them: row (b, w) of the
+    (B*nw, win*C) window matrix is the contiguous win*C floats at x[b, w*stride] (row map), the result is
+    TIME-major (nw, B, N).  x is data (no gradient); dW / db = one grouped TN launch over the same row map."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, win, stride):
+        _need_gpu(x, w)
+        x = x.contiguous()
+        B, T, Cc = x.shape
+        nw = (T - win) // stride + 1
+        K = win * Cc
+        wc = w.contiguous()
+        N = wc.shape[0]
+        if wc.shape[1] != K:
+            raise ValueError(f'weight expects {wc.shape[1]} inputs, windows have win_size * channels = {K}')
+        out = torch.empty(nw, B, N, dtype=_f32, device=x.device)
+        gemm_nt(x, wc, out, nw * B, N, K, bias=b, ra=rowmap(stride * Cc, rpg=nw, gs=T * Cc),
+                rc=rowmap(B * N, rpg=nw, gs=N))
+        ctx.save_for_backward(x)
+        ctx.params = (w, b)
+        ctx.dims = (B, T, Cc, nw, K, N, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.params
+        B, T, Cc, nw, K, N, stride = ctx.dims
+        dev = x.device
+        dout = dout.contiguous()
+        dw, acc_w, rw = _grad_target(w, (N, K), dev)
+        db = rb = None
+        if b is not None:
+            db, acc_b, rb = _grad_target(b, (N,), dev)
+            if acc_b != acc_w:
+                dw, db = torch.empty(N, K, dtype=_f32, device=dev), torch.empty(N, dtype=_f32, device=dev)
+                acc_w, rw, rb = False, dw, db
+        # A rows are time-major (w, b) in dout; the matching window row (b, w) of x comes through the row maps
+        gemm_tn_grouped([tn_problem(dout, x, dw, N, K, nw * B, ra=rowmap(B * N, rpg=nw, gs=N),
+                                    rb=rowmap(stride * Cc, rpg=nw, gs=T * Cc), colsum_out=db, accumulate=acc_w)], dev)
+        return None, rw, rb, None, None
+
+
 # --------------------------------------------------------------------------- #
 # optimiser                                                                    #
 # --------------------------------------------------------------------------- #

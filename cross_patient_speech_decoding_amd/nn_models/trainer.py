@@ -178,13 +178,24 @@ class Trainer:
 
     def _setup_optimizer(self, model):
         cfg = model.configure_optimizers()
-        opt = cfg['optimizer'] if isinstance(cfg, dict) else cfg
+        sched = None
+        if isinstance(cfg, dict):
+            opt = cfg['optimizer']
+            if 'lr_scheduler' in cfg:
+                sched = cfg['lr_scheduler']['scheduler']
+        elif isinstance(cfg, (tuple, list)):             # Lightning's ([optimizers], [schedulers]) form
+            opts, scheds = (cfg[0], cfg[1]) if len(cfg) == 2 and isinstance(cfg[0], (tuple, list)) else (cfg, [])
+            if len(opts) != 1 or len(scheds) > 1:
+                raise NotImplementedError('the HIP trainer drives one optimizer (and at most one scheduler)')
+            opt, sched = opts[0], (scheds[0] if scheds else None)
+        else:
+            opt = cfg
         g = opt.param_groups[0]
         self.optimizer = FlatAdamW(model, lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'],
                                    max_norm=self.gradient_clip_val, group=self.group)
         self.scheduler = None
-        if isinstance(cfg, dict) and 'lr_scheduler' in cfg:
-            sch = cfg['lr_scheduler']['scheduler']
+        if sched is not None:
+            sch = sched
             if isinstance(sch, torch.optim.lr_scheduler.LinearLR):
                 self.scheduler = LinearLR(self.optimizer, sch.start_factor, sch.end_factor, sch.total_iters)
             else:
@@ -205,12 +216,13 @@ class Trainer:
         model.eval()
         sums, count = {}, 0
         with torch.no_grad():
-            for bi, (x, y) in enumerate(loader):
-                x, y = _shard(x, rank, world).to(dev), _shard(y, rank, world).to(dev)
+            for bi, batch in enumerate(loader):
+                batch = tuple(_shard(t, rank, world).to(dev) for t in batch)
+                x = batch[0]
                 if x.shape[0] == 0:
                     continue
                 model._xps_logged = {}
-                getattr(model, f'{stage}_step' if stage != 'val' else 'validation_step')((x, y), bi)
+                getattr(model, f'{stage}_step' if stage != 'val' else 'validation_step')(batch, bi)
                 n = x.shape[0]
                 for k, v in model._xps_logged.items():
                     sums[k] = sums.get(k, 0.0) + float(v) * n
@@ -232,14 +244,15 @@ class Trainer:
             self.current_epoch = epoch
             model.train()
             sums, count = {}, 0
-            for bi, (x, y) in enumerate(train_dataloaders):
-                n_global = x.shape[0]
-                x, y = _shard(x, rank, world).to(dev), _shard(y, rank, world).to(dev)
+            for bi, batch in enumerate(train_dataloaders):
+                n_global = batch[0].shape[0]
+                batch = tuple(_shard(t, rank, world).to(dev) for t in batch)      # (x, y) or (x, y, lengths...)
+                x = batch[0]
                 if hasattr(model, 'temporal_conv'):
                     model.temporal_conv.global_batch = n_global
                 model._xps_logged = {}
                 self.optimizer.zero_grad()
-                loss = model.training_step((x, y), bi)
+                loss = model.training_step(batch, bi)
                 if world > 1:                       # global mean over unequal shards
                     loss = loss * (x.shape[0] * world / n_global)
                 loss.backward()

@@ -3,8 +3,9 @@ realtime_sim/realtime_nn_model.py (StackedRNN :22, DenseClassifier :66, Realtime
 forward :153, reformat_time_windows :172).  BASELINE config 5: per-step GRU inference captured in a
 hipGraph.
 
-Scope: inference (forward) with the reference's parameter names (``rnn.rnn.*``, ``h0``,
-``classifier.fc.*``) so reference checkpoints load; CTC training stays out of scope.
+Scope: forward with the reference's parameter names (``rnn.rnn.*``, ``h0``,
+``classifier.fc.*``) so reference checkpoints load, and CTC training (training/validation/test steps,
+fused CTC loss kernel, PER).
 
 * ``forward(x)``: the right-aligned sliding windows are never materialised — window w of trial b is the
   contiguous ``win*C`` floats at ``x[b, w*stride]``, read by the input-projection GEMM through a row map;
@@ -17,7 +18,8 @@ import torch.nn as nn
 
 from ..nn_models import functional as XF
 from ..nn_models._lightning import LightningModule
-from .._lib import rowmap
+from .._lib import rowmap  # noqa: F401
+from .ctc_decoder import greedy_decode_batch
 
 
 class StackedRNN(nn.Module):
@@ -39,6 +41,36 @@ def _layer_params(rnn, layer, ndir):
         sfx = f'_l{layer}' + ('_reverse' if d else '')
         out.append(tuple(getattr(rnn, n + sfx) for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')))
     return out
+
+
+class _HipCTCLoss(nn.CTCLoss):
+    """nn.CTCLoss whose default configuration dispatches to the fused HIP kernel.  Takes (T, B, C) log-probs as
+    nn.CTCLoss does (the kernel re-normalises: a no-op on log-probabilities)."""
+
+    def forward(self, log_probs, targets, input_lengths, target_lengths):
+        if self.reduction == 'mean' and log_probs.is_cuda and log_probs.dim() == 3 and targets.dim() == 2:
+            return XF.ctc_loss(log_probs, targets, input_lengths, target_lengths, blank=self.blank,
+                               zero_infinity=self.zero_infinity)
+        return super().forward(log_probs, targets, input_lengths, target_lengths)
+
+
+def edit_distance(a, b):
+    """Levenshtein distance of two label sequences (torchaudio.functional.edit_distance)."""
+    a, b = [int(v) for v in a], [int(v) for v in b]
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def calc_PER(decoded, targets, target_lengths):
+    """Phoneme error rate in percent (reference :303-324)."""
+    targets, target_lengths = targets.cpu(), target_lengths.cpu()
+    dist = sum(edit_distance(p.cpu().tolist(), t[:int(l)].tolist()) for p, t, l in zip(decoded, targets, target_lengths))
+    return dist / float(target_lengths.sum()) * 100
 
 
 class RealtimeRNNModel(LightningModule):
@@ -63,37 +95,78 @@ class RealtimeRNNModel(LightningModule):
             self.classifier.fc.bias[:] = -2.0
             self.classifier.fc.bias[blank] = 2.0
         self.win_size, self.stride, self.blank = win_size, stride, blank
+        self.criterion = _HipCTCLoss(blank=blank, zero_infinity=True)
 
     def n_windows(self, T):
         return (T - self.win_size) // self.stride + 1
 
-    @torch.no_grad()
-    def forward(self, x):
-        """x (B, T, C) -> logits (B, n_windows, n_classes)."""
+    def forward_tm(self, x):
+        """x (B, T, C) -> TIME-major logits (n_windows, B, n_classes); differentiable (weights and h0)."""
         rnn = self.rnn.rnn
         ndir = 2 if rnn.bidirectional else 1
         H, L = rnn.hidden_size, rnn.num_layers
         x = x.contiguous()
         B, T, Cc = x.shape
         nw = self.n_windows(T)
-        K = self.win_size * Cc
-        if K != rnn.input_size:
-            raise ValueError(f'input_size {rnn.input_size} != win_size * channels = {K}')
-        inp, inp_dim = None, K
+        if self.win_size * Cc != rnn.input_size:
+            raise ValueError(f'input_size {rnn.input_size} != win_size * channels = {self.win_size * Cc}')
+        inp = None
         for l in range(L):
             params = _layer_params(rnn, l, ndir)
-            gi = torch.empty(ndir, nw, B, 3 * H, dtype=torch.float32, device=x.device)
-            for d, (w_ih, _, b_ih, _) in enumerate(params):
-                if l == 0:      # window rows (b, w) -> time-major rows (w, b)
-                    XF.gemm_nt(x, w_ih.contiguous(), gi[d], nw * B, 3 * H, K, bias=b_ih,
-                               ra=rowmap(self.stride * Cc, rpg=nw, gs=T * Cc), rc=rowmap(B * 3 * H, rpg=nw, gs=3 * H))
-                else:
-                    XF.gemm_nt(inp, w_ih.contiguous(), gi[d], nw * B, 3 * H, inp_dim, bias=b_ih)
+            if l == 0:          # windows addressed through a row map, never materialised
+                gis = [XF.WindowLinearFn.apply(x, w_ih, b_ih, self.win_size, self.stride) for w_ih, _, b_ih, _ in params]
+            else:
+                gis = [XF.linear(inp, w_ih, b_ih) for w_ih, _, b_ih, _ in params]
+            gi = gis[0].unsqueeze(0) if ndir == 1 else torch.stack(gis, dim=0)
             h0 = self.h0[l * ndir:(l + 1) * ndir].expand(-1, B, -1).contiguous()
             y_ext = XF.GRURecurFn.apply(gi, h0, ndir, *[p[1] for p in params], *[p[3] for p in params])
-            inp, inp_dim = y_ext[1:nw + 1].contiguous(), ndir * H
-        logits = XF.linear(inp, self.classifier.fc.weight, self.classifier.fc.bias)     # (nw, B, C)
-        return logits.permute(1, 0, 2).contiguous()
+            inp = y_ext[1:nw + 1]
+            if l < L - 1:       # nn.GRU: dropout on the outputs of every layer but the last
+                inp = XF.dropout(inp, rnn.dropout, self.training)
+        return XF.linear(inp.contiguous(), self.classifier.fc.weight, self.classifier.fc.bias)     # (nw, B, C)
+
+    def forward(self, x):
+        """x (B, T, C) -> logits (B, n_windows, n_classes)  (reference :153-170)."""
+        return self.forward_tm(x).permute(1, 0, 2).contiguous()
+
+    # ---- training (reference :201-300): CTC loss on the window outputs, PER on validation -------------------
+    def _adjusted_lengths(self, input_lengths):
+        return ((input_lengths - self.win_size) // self.stride) + 1
+
+    def _ctc(self, batch, adjust=True):
+        inputs, targets, input_lengths, target_lengths = batch
+        il = self._adjusted_lengths(input_lengths) if adjust else input_lengths
+        logits_tm = self.forward_tm(inputs)
+        # the fused kernel takes raw time-major scores (the log-softmax is inside): same value as
+        # criterion(log_softmax(logits).permute(1, 0, 2), ...) without the (B, T, C) log-prob tensor
+        loss = XF.ctc_loss(logits_tm, targets, il, target_lengths, blank=self.blank, zero_infinity=True)
+        return loss, logits_tm
+
+    def training_step(self, batch, batch_idx):
+        loss, _ = self._ctc(batch)
+        self.log('train_loss', loss, on_step=False, on_epoch=True, prog_bar=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        loss, logits_tm = self._ctc(batch)
+        self.log('val_loss', loss, on_step=False, on_epoch=True, prog_bar=True)
+        with torch.no_grad():
+            decoded = greedy_decode_batch(logits_tm.permute(1, 0, 2), blank=self.blank)   # argmax: softmax-invariant
+            per = calc_PER(decoded, batch[1], batch[3])
+            self.log('val_PER', per, on_step=False, on_epoch=True, prog_bar=True)
+        return loss
+
+    def test_step(self, batch, batch_idx):
+        loss, _ = self._ctc(batch, adjust=False)           # the reference passes the raw lengths here (:283-286)
+        self.log('test_loss', loss)
+        return loss
+
+    def configure_optimizers(self):
+        hp = self.hparams_
+        optimizer = torch.optim.AdamW(self.parameters(), lr=hp['learning_rate'], weight_decay=hp['weight_decay'])
+        scheduler = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=1.0, end_factor=0.0,
+                                                      total_iters=hp['decay_steps'])
+        return [optimizer], [scheduler]
 
     def reformat_time_windows(self, x):
         """(B, T, C) -> (B, n_windows, win*C) right-aligned windows (materialised; for inspection only)."""

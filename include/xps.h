@@ -230,6 +230,16 @@ int xps_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float*
                               float* loss, int64_t rows, int n_classes, void* stream);
 int xps_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* gout,
                               float* dlogits, int64_t rows, int n_classes, void* stream);
+/* CTC loss of the realtime CTC-RNN family (realtime_sim/realtime_nn_model.py:150, :213-224:
+ * nn.CTCLoss(blank, reduction='mean', zero_infinity) on log_softmax(logits)).  logits [T][B][C] TIME-major raw
+ * scores (the log-softmax is fused); targets [B][target_stride] int64 (padded); lengths int64 [B].
+ * nll [B] per-sample negative log-likelihood; loss[0] = mean_b(nll_b / max(L_b, 1)); dlogits (optional, [T][B][C])
+ * = d loss[0] / d logits.  One launch for the batch; workspace holds the alpha lattice.                          */
+size_t xps_ctc_loss_f32_workspace(int T, int B, int max_target_len);
+int xps_ctc_loss_f32(const float* logits, const int64_t* targets, int64_t target_stride,
+                     const int64_t* input_lengths, const int64_t* target_lengths, int T, int B, int C,
+                     int max_target_len, int blank, int zero_infinity, float* nll, float* loss,
+                     float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
 /* sumsq[0] = sum g^2 over the flat gradient (deterministic two-stage) */
 size_t xps_sumsq_f32_workspace(int64_t n);
 int xps_sumsq_f32(const float* g, int64_t n, float* sumsq, void* workspace, size_t workspace_bytes,

@@ -41,3 +41,29 @@ def greedy_decode_batch(log_probs, blank=0):    # ctc_decoder.py:172-189
         keep[1:] = p[1:] != p[:-1]
         out.append(p[keep & (p != blank)])
     return out
+
+
+def ctc_step_loss(model, batch, adjust=True, blank=0):
+    """training_step / validation_step loss of the reference (realtime_nn_model.py:201-232): the input lengths are
+    converted to window counts, log_softmax over classes, nn.CTCLoss(blank, zero_infinity=True) on (T, B, C).
+    ``adjust=False`` is test_step (:283-286), which hands the lengths over as they are."""
+    inputs, targets, input_lengths, target_lengths = batch
+    il = ((input_lengths - model.win) // model.stride) + 1 if adjust else input_lengths
+    log_probs = model(inputs).log_softmax(2).permute(1, 0, 2)
+    return nn.CTCLoss(blank=blank, zero_infinity=True)(log_probs, targets, il, target_lengths)
+
+
+def edit_distance(a, b):
+    a, b = [int(v) for v in a], [int(v) for v in b]
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def calc_per(decoded, targets, target_lengths):                 # :303-324
+    dist = sum(edit_distance(p.tolist(), t[:int(l)].tolist()) for p, t, l in zip(decoded, targets, target_lengths))
+    return dist / float(target_lengths.sum()) * 100
