@@ -274,6 +274,130 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ 
     }
 }
 
+// Block one-sided Jacobi for large n without V.  The per-pair kernel above streams the whole matrix through HBM /
+// Infinity Cache once per round (n - 1 rounds per sweep: 8 MB x 1023 at n = 1024, bandwidth-bound at ~8 us a round).
+// Here the columns are grouped in blocks of JB = 8; a workgroup loads TWO blocks (16 columns, 128 KB of LDS),
+// rotates all JB x JB cross pairs in JB conflict-free inner rounds (wave w keeps column I_w in registers and meets
+// J_{(w+r) mod JB} in inner round r), and writes the blocks back: one pass over the matrix per JB inner rounds, and
+// n/JB - 1 launches per sweep instead of n - 1.  The pairs INSIDE a block are rotated by one extra launch per
+// sweep (WITHIN mode: blocks 2j and 2j+1, round-robin over the 8 columns of each).  Every pair is visited exactly
+// once per sweep, so the sweep counts are those of the cyclic orderings.
+constexpr int JB = 8, JB_MAXM = 1024, JB_EPL = JB_MAXM / 64;
+template <bool CROSS>
+__global__ __launch_bounds__(512) void jacobi_block_kernel(double* __restrict__ W, long long ldw, int m, int n, int nb,
+                                                           int round, unsigned long long* __restrict__ off_bits) {
+    extern __shared__ double jcols[];                      // [2 * JB][m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int I, J;
+    if (CROSS) rr_pair(nb, round, blockIdx.x, I, J);
+    else { I = 2 * blockIdx.x; J = I + 1; }
+    const int base[2] = {I * JB, J * JB};
+    if (base[0] >= n && base[1] >= n) return;
+    if (CROSS && (base[0] >= n || base[1] >= n)) return;   // phantom partner: nothing to rotate
+    // load the (up to) 16 columns; wave w loads columns w and w + 8
+    for (int c = wave; c < 2 * JB; c += 8) {
+        const int g = base[c / JB] + (c % JB);
+        double* dst = jcols + (size_t)c * m;
+        if (g < n) {
+            const double* src = W + (long long)g * ldw;
+            for (int i = lane; i < m; i += 64) dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    double offmax = 0.0;
+    if (CROSS) {
+        const int gi = base[0] + wave;                    // this wave's resident column (block I)
+        const bool have_x = gi < n;
+        double x[JB_EPL];
+#pragma unroll
+        for (int e = 0; e < JB_EPL; ++e) {
+            const int i = lane + 64 * e;
+            x[e] = (have_x && i < m) ? jcols[(size_t)wave * m + i] : 0.0;
+        }
+        for (int r = 0; r < JB; ++r) {
+            const int pj = (wave + r) % JB;
+            const bool act = have_x && (base[1] + pj < n);
+            double* yc = jcols + (size_t)(JB + pj) * m;
+            if (act) {
+                double y[JB_EPL];
+                double a = 0.0, b = 0.0, g = 0.0;
+#pragma unroll
+                for (int e = 0; e < JB_EPL; ++e) {
+                    const int i = lane + 64 * e;
+                    y[e] = i < m ? yc[i] : 0.0;
+                    a += x[e] * x[e]; b += y[e] * y[e]; g += x[e] * y[e];
+                }
+                a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+                double c, s, rel;
+                jacobi_angle(a, b, g, c, s, rel);
+                offmax = fmax(offmax, rel);
+                if (s != 0.0) {
+#pragma unroll
+                    for (int e = 0; e < JB_EPL; ++e) {
+                        const int i = lane + 64 * e;
+                        const double xv = x[e], yv = y[e];
+                        x[e] = c * xv - s * yv;
+                        if (i < m) yc[i] = s * xv + c * yv;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (have_x) {
+#pragma unroll
+            for (int e = 0; e < JB_EPL; ++e) {
+                const int i = lane + 64 * e;
+                if (i < m) jcols[(size_t)wave * m + i] = x[e];
+            }
+        }
+    } else {
+        const int half = wave >> 2, pw = wave & 3;        // waves 0-3: pairs inside block I, 4-7: inside block J
+        for (int r = 0; r < JB - 1; ++r) {
+            int p, q;
+            rr_pair(JB, r, pw, p, q);
+            const bool act = base[half] + q < n;           // p < q
+            double* pc = jcols + (size_t)(half * JB + p) * m;
+            double* qc = jcols + (size_t)(half * JB + q) * m;
+            if (act) {
+                double x[JB_EPL], y[JB_EPL];
+                double a = 0.0, b = 0.0, g = 0.0;
+#pragma unroll
+                for (int e = 0; e < JB_EPL; ++e) {
+                    const int i = lane + 64 * e;
+                    x[e] = i < m ? pc[i] : 0.0;
+                    y[e] = i < m ? qc[i] : 0.0;
+                    a += x[e] * x[e]; b += y[e] * y[e]; g += x[e] * y[e];
+                }
+                a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+                double c, s, rel;
+                jacobi_angle(a, b, g, c, s, rel);
+                offmax = fmax(offmax, rel);
+                if (s != 0.0) {
+#pragma unroll
+                    for (int e = 0; e < JB_EPL; ++e) {
+                        const int i = lane + 64 * e;
+                        if (i < m) {
+                            pc[i] = c * x[e] - s * y[e];
+                            qc[i] = s * x[e] + c * y[e];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int c = wave; c < 2 * JB; c += 8) {
+        const int g = base[c / JB] + (c % JB);
+        if (g < n) {
+            double* dst = W + (long long)g * ldw;
+            const double* src = jcols + (size_t)c * m;
+            for (int i = lane; i < m; i += 64) dst[i] = src[i];
+        }
+    }
+    if (off_bits && lane == 0 && offmax > 0.0) atomicMax(off_bits, (unsigned long long)__double_as_longlong(offmax));
+}
+
 // Whole decomposition of a SMALL matrix (n <= 128 columns) in ONE launch: one workgroup per matrix of the
 // batch, W (and V when it fits) live in LDS, 8 lanes per column pair, all sweeps and the convergence test run
 // inside the kernel (the per-round launch version spends ~6 us per round: 6 ms for a 128 x 128 eigenproblem).
@@ -576,6 +700,22 @@ extern "C" int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t 
         if (off && hipMemsetAsync(off, 0, sizeof(double), st) != hipSuccess) return XPS_E_HIP;
         return XPS_OK;
     }
+    const bool block_path = (V == nullptr) && m <= JB_MAXM && n > 4 * JB;
+    const int nb = ((n + JB - 1) / JB + 1) & ~1;         // blocks, padded to an even count
+    const size_t block_lds = (size_t)2 * JB * m * sizeof(double);
+    if (block_path) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_block_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * JB * JB_MAXM * (int)sizeof(double)) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_block_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * JB * JB_MAXM * (int)sizeof(double)) != hipSuccess) {
+                xps_set_error("xps_jacobi_sweeps_f64: cannot raise the dynamic LDS limit");
+                return XPS_E_HIP;
+            }
+            attr_set = true;
+        }
+    }
     for (int s = 0; s < sweeps; ++s) {
         const bool last = (s == sweeps - 1);
         if (last && off) {
@@ -583,6 +723,16 @@ extern "C" int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t 
                 xps_set_error("xps_jacobi_sweeps_f64: memset failed");
                 return XPS_E_HIP;
             }
+        }
+        if (block_path) {
+            unsigned long long* ob = (last && off) ? (unsigned long long*)off : nullptr;
+            hipLaunchKernelGGL(jacobi_block_kernel<false>, dim3(nb / 2), dim3(512), block_lds, st, W, (long long)ldw, m, n, nb,
+                               0, ob);
+            for (int r = 0; r < nb - 1; ++r)
+                hipLaunchKernelGGL(jacobi_block_kernel<true>, dim3(nb / 2), dim3(512), block_lds, st, W, (long long)ldw, m, n,
+                                   nb, r, ob);
+            XPS_CHECK_LAUNCH();
+            continue;
         }
         for (int r = 0; r < ne - 1; ++r) {
             launch_jacobi_round(W, (long long)ldw, V, (long long)ldv, m, n, ne, r,
