@@ -394,6 +394,9 @@ class GRULayerFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- #
 # TemporalConv: Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                      #
 # --------------------------------------------------------------------------- #
+POST_SYNCBN_HOOKS = []
+
+
 def _group_world(group):
     import torch.distributed as dist
     if group is not None and dist.is_available() and dist.is_initialized():
@@ -479,6 +482,10 @@ class TemporalConvFn(torch.autograd.Function):
         if _group_world(group) > 1:             # SyncBN: the dy formula needs the global sums, the
             local = sums.clone()                # parameter gradients the local ones (averaged with the rest later)
             _dist_sum_(sums, group)
+            # every gradient downstream of this layer is enqueued by now: a data-parallel optimiser may start
+            # reducing them (AFTER the statistics exchange above, so that it never queues behind a large one)
+            for hook in list(POST_SYNCBN_HOOKS):
+                hook()
         else:
             local = sums
         dbeta, dgamma = local[:F], local[F:]

@@ -67,9 +67,44 @@ class FlatAdamW:
         self.betas, self.eps, self.weight_decay, self.max_norm = betas, eps, weight_decay, max_norm
         self.group = group
         self.step_count = 0
+        # data-parallel overlap: the gradients of everything downstream of `module.temporal_conv` are complete
+        # before the convolution's own backward starts; their slice of the flat buffer is all-reduced
+        # asynchronously while that backward (~8 % of the step) runs.  The trigger sits right after the SyncBN
+        # statistics exchange of the backward pass (functional.POST_SYNCBN_HOOKS): one communicator, and the
+        # small latency-critical exchange is never queued behind the large one.  XPS_DP_OVERLAP=0 disables.
+        self._split = None
+        self._early = None
+        import os
+        world, _ = _world(group)
+        if (world > 1 and os.environ.get('XPS_DP_OVERLAP', '1') != '0' and XF.DIRECT_GRAD
+                and hasattr(module, 'temporal_conv')):
+            first = {id(p) for p in module.temporal_conv.parameters()}
+            idx = [i for i, p in enumerate(self.params) if id(p) not in first]
+            if idx and idx == list(range(idx[0], len(self.params))) and idx[0] > 0:
+                self._split = offs[idx[0]]
+                XF.POST_SYNCBN_HOOKS[:] = [self._reduce_tail_async]       # one optimiser drives the model
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
+
+    def _reduce_tail_async(self):
+        """Hook (autograd thread, during backward): all-reduce flat_g[split:] without blocking the main stream.
+        Issued from the side stream that carries the weight-gradient GEMMs so that it waits for them."""
+        if self._early is not None:
+            return
+        # only valid while every gradient of the tail lives in the flat buffer (direct accumulation)
+        for p, view in zip(self.params, self._grad_views):
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                return
+        dev = self.flat_g.device
+        side = XF._side_streams.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        tail = self.flat_g[self._split:]
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))       # gradients written on the main stream too
+            with torch.cuda.stream(side):
+                self._early = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._early = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()
     def step(self):
@@ -86,7 +121,12 @@ class FlatAdamW:
                 view.copy_(p.grad)
                 p.grad = view
         if world > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            if self._early is not None:                    # the tail went out during backward: only the head is left
+                dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=self.group)
+                self._early.wait()
+                self._early = None
+            else:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_g.mul_(1.0 / world)
         self.step_count += 1
         XF.grad_sumsq(self.flat_g, out=self.sumsq)

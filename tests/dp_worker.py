@@ -45,7 +45,8 @@ def hip_step(rank, world, X, y, group):
     loss.backward()
     opt.step()
     gnorm = opt.grad_norm()
-    return opt.flat_g.clone().cpu(), opt.flat_p.clone().cpu(), float(gnorm), m.temporal_conv.bn.running_var.cpu()
+    # numpy (pickled by value): torch tensors would travel as file descriptors of a process that may be gone
+    return (opt.flat_g.cpu().numpy(), opt.flat_p.cpu().numpy(), float(gnorm), m.temporal_conv.bn.running_var.cpu().numpy())
 
 
 def worker(rank, world, device, q):
@@ -101,8 +102,8 @@ def main():
         assert p.exitcode == 0, p.exitcode
     if a.device == 'cuda':
         X, y = data()
-        g1, p1, n1, rv1 = hip_step(0, 1, X, y, None)
-        g2, p2, n2, rv2 = res
+        g1, p1, n1, rv1 = [torch.as_tensor(v) if not isinstance(v, float) else v for v in hip_step(0, 1, X, y, None)]
+        g2, p2, n2, rv2 = [torch.as_tensor(v) if not isinstance(v, float) else v for v in res]
         eg = (g1 - g2).abs().max().item() / max(g1.abs().max().item(), 1e-12)
         assert eg < 2e-4, f'gradient mismatch {eg}'
         assert abs(n1 - n2) < 2e-4 * n1, (n1, n2)
