@@ -74,8 +74,11 @@ class FlatAdamW:
         # small latency-critical exchange is never queued behind the large one.  XPS_DP_OVERLAP=0 disables.
         self._split = None
         self._early = None
-        import os
         world, _ = _world(group)
+        # RCCL averages in the collective (no extra pass over the buffer); gloo (CPU tests) sums, then one scale
+        self._avg = world > 1 and dist.get_backend(group) == 'nccl'
+        self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        import os
         if (world > 1 and os.environ.get('XPS_DP_OVERLAP', '1') != '0' and XF.DIRECT_GRAD
                 and hasattr(module, 'temporal_conv')):
             first = {id(p) for p in module.temporal_conv.parameters()}
@@ -102,9 +105,9 @@ class FlatAdamW:
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dev))       # gradients written on the main stream too
             with torch.cuda.stream(side):
-                self._early = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._early = dist.all_reduce(tail, op=self._op, group=self.group, async_op=True)
         else:
-            self._early = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._early = dist.all_reduce(tail, op=self._op, group=self.group, async_op=True)
 
     @torch.no_grad()
     def step(self):
@@ -122,12 +125,13 @@ class FlatAdamW:
                 p.grad = view
         if world > 1:
             if self._early is not None:                    # the tail went out during backward: only the head is left
-                dist.all_reduce(self.flat_g[:self._split], op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self.flat_g[:self._split], op=self._op, group=self.group)
                 self._early.wait()
                 self._early = None
             else:
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat_g.mul_(1.0 / world)
+                dist.all_reduce(self.flat_g, op=self._op, group=self.group)
+            if not self._avg:
+                self.flat_g.mul_(1.0 / world)
         self.step_count += 1
         XF.grad_sumsq(self.flat_g, out=self.sumsq)
         XF.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, self.max_norm or 0.0,
