@@ -38,6 +38,8 @@ _rm = C.POINTER(RowMap)
 SIGNATURES = {
     'xps_last_error': (C.c_char_p, []),
     'xps_abi_version': (_i, []),
+    'xps_stream_create_low_priority': (_i, [_vp]),
+    'xps_stream_destroy': (_i, [_vp]),
     'xps_gemm_nt_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),
     'xps_gemm_nn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp]),
     'xps_gemm_nt_multi_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),

@@ -102,6 +102,16 @@ _side_streams = {}
 _side_pending = set()
 
 
+def _low_priority_stream(idx):
+    """Side stream BELOW the default priority (torch only offers default / high): when a CU frees up, kernels of
+    the critical path are dispatched first; measured without it, tiny main-stream kernels queued up to 100 us
+    behind the side stream's GEMM blocks."""
+    handle = C.c_void_p()
+    with torch.cuda.device(idx):
+        call('xps_stream_create_low_priority', C.byref(handle))
+    return torch.cuda.ExternalStream(handle.value, device=idx)
+
+
 def _join_side_streams():
     for dev_index in list(_side_pending):
         torch.cuda.current_stream(dev_index).wait_stream(_side_streams[dev_index])
@@ -116,7 +126,7 @@ def _launch_weight_grads(fn, device, tensors, direct):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     side = _side_streams.get(idx)
     if side is None:
-        side = _side_streams[idx] = torch.cuda.Stream(device=idx)
+        side = _side_streams[idx] = _low_priority_stream(idx)
     side.wait_stream(torch.cuda.current_stream(idx))
     with torch.cuda.stream(side):
         fn()
@@ -205,7 +215,9 @@ class LinearFn(torch.autograd.Function):
                     dw = torch.empty(N, K, dtype=_f32, device=dy.device)
                     db = torch.empty(N, dtype=_f32, device=dy.device)
                     acc_w, rw, rb = False, dw, db
-            gemm_tn_grouped([tn_problem(dy2, x2, dw, N, K, M, colsum_out=db, accumulate=acc_w)], dy.device)
+            prob = [tn_problem(dy2, x2, dw, N, K, M, colsum_out=db, accumulate=acc_w)]
+            _launch_weight_grads(lambda: gemm_tn_grouped(prob, dy.device), dy.device, (dy2, x2),
+                                 rw is None and (rb is None or not need_b))
             if not need_w:
                 rw = None
         return dx, rw, rb
@@ -362,15 +374,8 @@ class GRULayerFn(torch.autograd.Function):
         wb = ctx.params
         dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False)
         dev = x.device
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(T, B, In, dtype=_f32, device=dev)
-            if ndir == 2:       # both directions summed in registers: one launch, no accumulate pass over dx
-                ra, rb, rc = rowmap(3 * H), rowmap(In), rowmap(In)
-                call('xps_gemm_nn2_f32', _ptr(dgi[0]), _ptr(w_ih[0]), 3 * H, _ptr(dgi[1]), _ptr(w_ih[1]), 3 * H,
-                     C.byref(ra), C.byref(rb), _ptr(dx), C.byref(rc), T * B, In, 0, _stream())
-            else:
-                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H)
+        # weight gradients first: on the side stream they depend on the recurrence kernel only, so they start
+        # together with the input-gradient GEMM below instead of after it (and are out of the way earlier)
         probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_ext, [wb[4 * d + 1] for d in range(ndir)],
                                                   [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir)
         rets_ih = []
@@ -385,6 +390,15 @@ class GRULayerFn(torch.autograd.Function):
             rets_ih.append((rw, rb))
         direct = all(r[0] is None and r[1] is None for r in rets_ih + rets_hh)
         _launch_weight_grads(lambda: gemm_tn_grouped(probs, dev), dev, (dgi, dghn, x, y_ext), direct)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, B, In, dtype=_f32, device=dev)
+            if ndir == 2:       # both directions summed in registers: one launch, no accumulate pass over dx
+                ra, rb, rc = rowmap(3 * H), rowmap(In), rowmap(In)
+                call('xps_gemm_nn2_f32', _ptr(dgi[0]), _ptr(w_ih[0]), 3 * H, _ptr(dgi[1]), _ptr(w_ih[1]), 3 * H,
+                     C.byref(ra), C.byref(rb), _ptr(dx), C.byref(rc), T * B, In, 0, _stream())
+            else:
+                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H)
         grads = []
         for d in range(ndir):
             grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]
@@ -583,7 +597,8 @@ class DecoderFn(torch.autograd.Function):
             tn_problem(dlogits, hnext, dwf, C, H, L * B, ra=rowmap(L * C, rpg=B, gs=C), rb=rowmap(H), rc=rowmap(H),
                        colsum_out=dbf, accumulate=acc_f),
         ]
-        gemm_tn_grouped(probs, dev)
+        _launch_weight_grads(lambda: gemm_tn_grouped(probs, dev), dev, (dgi, dghn, hs, dlogits),
+                             r_wh is None and r_bh is None and r_wf is None and r_bf is None)
         # d table[tok] += dgi over all (step, trial) rows
         dtable = torch.empty(ntok, 3 * H, dtype=_f32, device=dev)
         nbytes = lib().xps_scatter_rows_f32_workspace(L * B, 3 * H, ntok)

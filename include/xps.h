@@ -49,6 +49,9 @@ typedef struct xps_rowmap {
 
 const char* xps_last_error(void);
 int xps_abi_version(void);
+/* a HIP stream at the lowest priority of the device (for work that must yield to the caller's main stream) */
+int xps_stream_create_low_priority(void** stream);
+int xps_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Dense fp32 contractions on the f32-input MFMA (exact fp32 fma chains).      */
