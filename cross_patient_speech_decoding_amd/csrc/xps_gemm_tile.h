@@ -50,39 +50,63 @@ struct TileLoader {
     static constexpr int NV = KCONTIG ? W / XR : BKT / KR;
     const float* base[NV];
     long long xoff[NV];
-    long long kstride;
-    bool fast;
+    long long kstride, kgs;       // !KCONTIG: row stride inside a group / group stride of the k rows
+    int krpg;                     // !KCONTIG: k rows per group (0: plain leading dimension)
+    bool fast;                    // unguarded 16-byte loads are possible (alignment, row-map structure)
+    bool full;                    // ... and the W-wide x range lies entirely inside the matrix
+    bool ok[NV];                  // edge tiles: this thread's vector lies inside the matrix (else it reads as 0)
 
     __device__ inline void init(const float* __restrict__ P, const RowMap& rm, int x0, int X, int rows_k, int tid, bool vec) {
         if (KCONTIG) {
-            fast = vec && (x0 + W <= X);
+            // edge tiles (x0 + W > X) stay on the fast path: rows beyond the matrix are predicated off and read as 0
+            fast = vec;
+            full = x0 + W <= X;
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 const int x = x0 + tid / KL + XR * r;
                 xoff[r] = (x < X) ? rm.off(x) : -1;
+                ok[r] = x < X;
                 base[r] = P + (xoff[r] >= 0 ? xoff[r] : 0) + (tid % KL) * 4;
             }
             kstride = 1;
         } else {
-            fast = vec && (x0 + W <= X) && (rm.rpg >= rows_k);
+            // k rows under a two-level map stay on the fast path when a k-tile never straddles a group
+            // (rows per group a multiple of the tile depth; k-split chunks start on tile boundaries)
+            const bool plain = rm.rpg >= rows_k;
+            // edge tiles stay fast when whole 16-byte vectors are in or out (X % 4 == 0): out-of-range lanes read 0
+            full = x0 + W <= X;
+            fast = vec && (full || X % 4 == 0) && (plain || rm.rpg % BKT == 0);
+            const bool lane_in = x0 + (tid % XL) * 4 < X;
+#pragma unroll
+            for (int r = 0; r < NV; ++r) ok[r] = lane_in;
             kstride = rm.ld;
+            kgs = rm.gs;
+            krpg = plain ? 0 : rm.rpg;
 #pragma unroll
             for (int r = 0; r < NV; ++r)
-                base[r] = P + (long long)(tid / XL + KR * r) * rm.ld + x0 + (tid % XL) * 4;
+                base[r] = P + (long long)(tid / XL + KR * r) * rm.ld + (lane_in ? x0 + (tid % XL) * 4 : 0);
         }
     }
 
-    // unguarded 16-byte loads of a FULL k-tile (only valid when `fast`)
+    // unguarded 16-byte loads of a FULL k-tile (only valid when `fast`; EDGE = false additionally needs `full`).
+    // EDGE: vectors outside the matrix are predicated off and read as zero.
+    template <bool EDGE>
     __device__ inline void load_fast(f32x4 (&v)[NV], int kt0) const {
+        long long koff;                                   // block-uniform offset of the tile's first k row
+        if (KCONTIG) koff = kt0;
+        else if (krpg == 0) koff = (long long)kt0 * kstride;
+        else koff = (long long)(kt0 / krpg) * kgs + (long long)(kt0 % krpg) * kstride;
 #pragma unroll
-        for (int r = 0; r < NV; ++r)
-            v[r] = *reinterpret_cast<const f32x4*>(base[r] + (KCONTIG ? (long long)kt0 : (long long)kt0 * kstride));
+        for (int r = 0; r < NV; ++r) {
+            if (EDGE) v[r] = ok[r] ? *reinterpret_cast<const f32x4*>(base[r] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else v[r] = *reinterpret_cast<const f32x4*>(base[r] + koff);
+        }
     }
 
     __device__ inline void load(f32x4 (&v)[NV], const float* __restrict__ P, const RowMap& rm, int x0, int X,
                                 int kt0, int kend, int tid, bool vec) const {
-        if (fast && kt0 + BKT <= kend) {
-            load_fast(v, kt0);
+        if (fast && full && kt0 + BKT <= kend) {
+            load_fast<false>(v, kt0);
             return;
         }
         if (KCONTIG) {
@@ -148,7 +172,10 @@ struct TileLoader {
 // acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Pipeline: global
 // loads run TWO k-tiles ahead of the MFMAs (registers), LDS is double buffered, one barrier per k-tile.
 // csum (TN form, optional): running column sums of the staged A tile (bias gradient).
-template <bool AK, bool BK, int MI, bool FAST>
+// MODE 0: guarded loads (any shape / alignment; takes the unguarded path per tile when it can);  1: every k-tile full,
+// both operand tiles interior and aligned: no guards, no divergent paths in the k loop;  2: as 1 for EDGE tiles (vectors
+// outside the matrix predicated off).
+template <bool AK, bool BK, int MI, int MODE>
 __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
                                      const TileLoader<AK, 64 * MI>& la, const TileLoader<BK, 128>& lb,
                                      const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
@@ -158,7 +185,7 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float& csum, const bo
     using LA = TileLoader<AK, WM>;
     using LB = TileLoader<BK, 128>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // FAST: every k-tile in [kbeg, kend) is full and both operand tiles are interior + aligned: the k loop has
+    // MODE 1 / 2: every k-tile in [kbeg, kend) is full and both operand tiles are aligned: the k loop has
     // no guards and no divergent paths, so the compiler's waitcnt placement keeps two k-tiles of loads in flight
     // (a loop that also contains the guarded path gets conservative vmcnt(0) waits at every join)
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
@@ -167,10 +194,10 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float& csum, const bo
 
     f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
-        if (FAST) { la.load_fast(ra0, kbeg); lb.load_fast(rb0, kbeg); }
+        if (MODE) { la.template load_fast<MODE == 2>(ra0, kbeg); lb.template load_fast<MODE == 2>(rb0, kbeg); }
         else { la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB); }
         if (nkt > 1) {
-            if (FAST) { la.load_fast(ra1, kbeg + BKT); lb.load_fast(rb1, kbeg + BKT); }
+            if (MODE) { la.template load_fast<MODE == 2>(ra1, kbeg + BKT); lb.template load_fast<MODE == 2>(rb1, kbeg + BKT); }
             else { la.load(ra1, A, ra, m0, M, kbeg + BKT, kend, tid, vecA); lb.load(rb1, B, rb, n0, N, kbeg + BKT, kend, tid, vecB); }
         }
         la.store(ra0, As[0], tid);
@@ -185,7 +212,7 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float& csum, const bo
         const int buf = kt & 1;
         GSTAMP(g0)
         if (kt + 2 < nkt) {
-            if (FAST) { la.load_fast(ra0, kbeg + (kt + 2) * BKT); lb.load_fast(rb0, kbeg + (kt + 2) * BKT); }
+            if (MODE) { la.template load_fast<MODE == 2>(ra0, kbeg + (kt + 2) * BKT); lb.template load_fast<MODE == 2>(rb0, kbeg + (kt + 2) * BKT); }
             else { la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB); }
         }
         GSTAMP(g1)
@@ -244,14 +271,22 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float& csum, const 
     la.init(A, ra, m0, M, K, threadIdx.x, vecA);
     lb.init(B, rb, n0, N, K, threadIdx.x, vecB);
     const int kfull = kbeg + ((kend - kbeg) / BKT) * BKT;
-    // the split pays for the k-contiguous ([x][k]) operand form, whose guarded path is long (partial vector
-    // loads with their own waits); the [k][x] form is faster with the single combined loop
-    if (AK && BK && la.fast && lb.fast && kfull > kbeg) {
-        gemm_pipeline<AK, BK, MI, true>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
+    // Interior tiles: the k-contiguous (NT) form runs the branch-free pipeline over the full k-tiles and the guarded one
+    // over a ragged tail (its guarded path is long); the [k][x] forms are faster with the single combined loop.
+    // EDGE tiles (e.g. the 100-wide filter dimension in a 128-wide tile) used to fall to the guarded loop for the whole
+    // k range: they now run the predicated branch-free pipeline (+10 % on the F = 100 shapes of the model).
+    const bool both_fast = la.fast && lb.fast && kfull > kbeg;
+    const bool both_full = la.full && lb.full;
+    if (both_fast && both_full && AK && BK) {
+        gemm_pipeline<AK, BK, MI, 1>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
         if (kfull < kend)
-            gemm_pipeline<AK, BK, MI, false>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
+            gemm_pipeline<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
+    } else if (both_fast && !both_full) {
+        gemm_pipeline<AK, BK, MI, 2>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
+        if (kfull < kend)
+            gemm_pipeline<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
     } else {
-        gemm_pipeline<AK, BK, MI, false>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
+        gemm_pipeline<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
     }
 }
 

@@ -510,8 +510,11 @@ class TemporalConvFn(torch.autograd.Function):
         # column sums of dy, produced by the same launch
         dconv_b = torch.empty(F, dtype=_f32, device=dev)
         dw2 = torch.empty(F, k * Cin, dtype=_f32, device=dev)
-        gemm_tn_grouped([tn_problem(dy, x, dw2, F, k * Cin, rows, ra=rowmap(B * F, rpg=Tp, gs=F),
-                                    rb=rowmap(stride * Cin, rpg=Tp, gs=T * Cin), colsum_out=dconv_b)], dev)
+        # contraction rows in (t', b) order: dy is then a plain contiguous matrix and the window rows of x form
+        # groups of B rows (stride T*C) per t' (stride s*C) -- k-tiles never straddle a group when 16 | B, which
+        # keeps both operands on the unguarded load path
+        gemm_tn_grouped([tn_problem(dy, x, dw2, F, k * Cin, rows, ra=rowmap(F),
+                                    rb=rowmap(T * Cin, rpg=B, gs=stride * Cin), colsum_out=dconv_b)], dev)
         gw, acc_w, _ = _grad_target(ctx.conv_w, (F, Cin, k), dev)
         if acc_w:                               # un-permute and accumulate in one pass, straight into .grad
             gw.add_(dw2.view(F, k, Cin).permute(0, 2, 1))
@@ -824,9 +827,9 @@ class WindowLinearFn(torch.autograd.Function):
             if acc_b != acc_w:
                 dw, db = torch.empty(N, K, dtype=_f32, device=dev), torch.empty(N, dtype=_f32, device=dev)
                 acc_w, rw, rb = False, dw, db
-        # A rows are time-major (w, b) in dout; the matching window row (b, w) of x comes through the row maps
-        gemm_tn_grouped([tn_problem(dout, x, dw, N, K, nw * B, ra=rowmap(B * N, rpg=nw, gs=N),
-                                    rb=rowmap(stride * Cc, rpg=nw, gs=T * Cc), colsum_out=db, accumulate=acc_w)], dev)
+        # contraction rows in (w, b) order: dout is plain, the window rows of x are groups of B rows per window
+        gemm_tn_grouped([tn_problem(dout, x, dw, N, K, nw * B, ra=rowmap(N),
+                                    rb=rowmap(T * Cc, rpg=B, gs=stride * Cc), colsum_out=db, accumulate=acc_w)], dev)
         return None, rw, rb, None, None
 
 
