@@ -58,7 +58,7 @@ SIGNATURES = {
     'xps_bn_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
     'xps_bn_apply_eval_f32': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     'xps_bn_bwd_workspace': (_sz, [_i64, _i]),
-    'xps_bn_bwd_reduce_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i64, _i, _vp, _sz, _vp]),
+    'xps_bn_bwd_reduce_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
     'xps_bn_bwd_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _d, _vp, _i64, _i, _vp]),
     'xps_decoder_supported': (_i, [_i, _i, _i]),
     'xps_decoder_fwd_f32': (_i, [_vp] * 12 + [_i] * 6 + [_vp]),
@@ -79,6 +79,7 @@ SIGNATURES = {
     'xps_sumsq_f32_workspace': (_sz, [_i64]),
     'xps_sumsq_f32': (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
     'xps_adamw_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    'xps_clip_adamw_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp, _sz, _vp]),
     'xps_cnd_avg_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
     'xps_cnd_avg_f64': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
     'xps_colsum_f64_workspace': (_sz, [_i64, _i]),

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
         float s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
         const long long mn = (long long)P.M * P.N;
         float* dst = (e < mn) ? (P.C + P.rc.off((int)(e / P.N)) + (int)(e % P.N)) : (P.colsum + (e - mn));
-        if (P.accumulate) s += *dst;
+        // accumulate bit 0: products AND column sums add to their destinations; bit 1: the column sums only
+        if ((P.accumulate & 1) || ((P.accumulate & 2) && e >= mn)) s += *dst;
         *dst = s;
     }
 }

@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X
 constexpr int S2_GROUPS = 16;
 __global__ __launch_bounds__(1024) void colsum_stage2(const float* __restrict__ part, const float* __restrict__ part_sq,
                                                       int nparts, int cols, float* __restrict__ out,
-                                                      float* __restrict__ out_sq, int accumulate) {
+                                                      float* __restrict__ out_sq, int accumulate,
+                                                      float* __restrict__ acc_lo = nullptr, float* __restrict__ acc_hi = nullptr,
+                                                      int split = 0) {
     __shared__ float s1[S2_GROUPS][64], s2[S2_GROUPS][64];
     const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + l;
@@ -75,6 +77,10 @@ __global__ __launch_bounds__(1024) void colsum_stage2(const float* __restrict__ 
         }
         out[c] = a;
         if (out_sq) out_sq[c] = a2;
+        // optional: the same sums ADDED into two more vectors (columns < split / >= split): the BatchNorm
+        // bias / weight gradients go straight into the flat gradient buffer
+        if (acc_lo && c < split) acc_lo[c] += a;
+        if (acc_hi && c >= split) acc_hi[c - split] += a;
     }
 }
 
@@ -313,6 +319,33 @@ __global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__
     if (threadIdx.x == 0) loss[0] = (float)(sh[0] / (double)rows);
 }
 
+// rows <= CE_FUSED_ROWS: per-row losses and their mean in ONE single-block launch (each thread walks rows tid,
+// tid + 1024, ...; fixed-order tree).  The two-kernel form costs a second ~5 us launch for 6144 rows of 9 classes.
+constexpr int CE_FUSED_ROWS = 1024;      // one row per thread: beyond that the single block is latency-bound (6144 rows: 26 us vs 9.4 us for two launches)
+__global__ __launch_bounds__(1024) void ce_fused_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                        float* __restrict__ row_loss, float* __restrict__ loss, long long rows,
+                                                        int C) {
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (long long r = threadIdx.x; r < rows; r += 1024) {
+        const float* p = logits + r * C;
+        float mx = p[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(p[c] - mx);
+        const float l = (logf(s) + mx) - p[target[r]];
+        row_loss[r] = l;
+        a += (double)l;
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(sh[0] / (double)rows);
+}
+
 __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
                               const float* __restrict__ gout, float* __restrict__ dlogits, long long rows, int C) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,6 +394,42 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
     float coef = 1.f;
     if (max_norm > 0.f && sumsq) {
         const float c = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        g[i] = gi;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+// clip + AdamW with the second stage of the gradient-norm reduction folded in: every block folds the (few hundred)
+// partial sums in the same fixed order, block 0 publishes the total
+__global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, long long n, const double* __restrict__ part,
+                                                          int nparts, float* __restrict__ sumsq_out, float max_norm, float lr,
+                                                          float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float ss = (float)sh[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sumsq_out) sumsq_out[0] = ss;
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        const float c = max_norm / (sqrtf(ss) + 1e-6f);
         coef = c < 1.f ? c : 1.f;
     }
     const float step_size = lr / bc1;
@@ -452,8 +521,8 @@ extern "C" size_t xps_bn_bwd_workspace(int64_t rows, int F) {
 
 extern "C" int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const float* y, const float* mean,
                                      const float* rstd, const float* drop_mask, float drop_scale, int relu,
-                                     float* sums, int64_t rows, int F, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     float* sums, float* dbeta_acc, float* dgamma_acc, int64_t rows, int F,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
     XPS_CHECK_ARG(dout && y && mean && rstd && sums && rows >= 1 && F >= 1, "bad argument");
     XPS_CHECK_ARG(!relu || out, "relu backward needs the forward output");
     if (workspace_bytes < xps_bn_bwd_workspace(rows, F) || !workspace) {
@@ -466,7 +535,7 @@ extern "C" int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const 
                        dout, out, y, mean, rstd, drop_mask, drop_scale, relu, (long long)rows, F, part);
     XPS_CHECK_LAUNCH();
     hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(2 * F, 64)), dim3(1024), 0, (hipStream_t)stream,
-                       part, (const float*)nullptr, nparts, 2 * F, sums, (float*)nullptr, 0);
+                       part, (const float*)nullptr, nparts, 2 * F, sums, (float*)nullptr, 0, dbeta_acc, dgamma_acc, F);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
@@ -566,6 +635,12 @@ extern "C" int xps_add_f32(const float* a, const float* b, float* out, int64_t n
 extern "C" int xps_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float* row_loss, float* loss,
                                          int64_t rows, int n_classes, void* stream) {
     XPS_CHECK_ARG(logits && target && row_loss && loss && rows >= 1 && n_classes >= 1, "bad argument");
+    if (rows <= CE_FUSED_ROWS) {
+        hipLaunchKernelGGL(ce_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (const long long*)target,
+                           row_loss, loss, (long long)rows, n_classes);
+        XPS_CHECK_LAUNCH();
+        return XPS_OK;
+    }
     hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream,
                        logits, (const long long*)target, row_loss, (long long)rows, n_classes);
     XPS_CHECK_LAUNCH();
@@ -614,6 +689,27 @@ extern "C" int xps_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, sumsq,
                        max_norm, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_clip_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, float* sumsq, float max_norm, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int step, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "bad argument");
+    if (n == 0) return XPS_OK;
+    if (!workspace || workspace_bytes < xps_sumsq_f32_workspace(n)) {
+        xps_set_error("xps_clip_adamw_f32: workspace too small");
+        return XPS_E_WORKSPACE;
+    }
+    const int nparts = cdiv(n, SS_CHUNK);
+    hipLaunchKernelGGL(sumsq_stage1, dim3(nparts), dim3(256), 0, (hipStream_t)stream, g, (long long)n, (double*)workspace);
+    XPS_CHECK_LAUNCH();
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_fused_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                       (const double*)workspace, nparts, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                       (float)sqrt(bc2));
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

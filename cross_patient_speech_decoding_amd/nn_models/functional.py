@@ -75,10 +75,12 @@ def gemm_tn(A, B, out, M, N, K, ra=None, rb=None, rc=None, accumulate=False):
     return out
 
 
-def tn_problem(A, B, out, M, N, K, ra=None, rb=None, rc=None, colsum_out=None, accumulate=False):
-    """One weight-gradient problem  out (+)= A^T B  (A: K x M, B: K x N) [+ colsum_out (+)= column sums of A]."""
+def tn_problem(A, B, out, M, N, K, ra=None, rb=None, rc=None, colsum_out=None, accumulate=False,
+               accumulate_colsum=False):
+    """One weight-gradient problem  out (+)= A^T B  (A: K x M, B: K x N) [+ colsum_out (+)= column sums of A].
+    ``accumulate`` makes both destinations accumulate; ``accumulate_colsum`` the column sums alone."""
     return TnProblem(_ptr(A), _ptr(B), _ptr(out), _ptr(colsum_out), ra or rowmap(M), rb or rowmap(N),
-                     rc or rowmap(N), M, N, K, int(accumulate))
+                     rc or rowmap(N), M, N, K, int(bool(accumulate)) | (2 if accumulate_colsum else 0))
 
 
 def gemm_tn_grouped(problems, device):
@@ -476,6 +478,8 @@ class TemporalConvFn(torch.autograd.Function):
             ctx.save_for_backward(x, w2, y, out, mean, rstd, gamma, drop_mask)
             ctx.cfg = (B, T, Cin, F, k, stride, Tp, relu, drop_scale, count, group)
             ctx.conv_w = conv_w
+            ctx.conv_b = conv_b
+            ctx.bn_params = (gamma, beta)
         else:
             call('xps_bn_apply_eval_f32', _ptr(y), _ptr(running_mean), _ptr(running_var), eps, _ptr(gamma),
                  _ptr(beta), _ptr(out), rows, F, int(relu), _stream())
@@ -491,37 +495,47 @@ class TemporalConvFn(torch.autograd.Function):
         sums = torch.empty(2 * F, dtype=_f32, device=dev)
         nbytes = lib().xps_bn_bwd_workspace(rows, F)
         ws = _ws(nbytes, dev)
+        # BatchNorm parameter gradients = the LOCAL sums: added straight into the .grad buffers by the reduction
+        # kernel when they exist (no clone, no add launches), else handed to autograd as slices
+        g_beta, acc_beta, _ = _grad_target(ctx.bn_params[1], (F,), dev)
+        g_gamma, acc_gamma, _ = _grad_target(ctx.bn_params[0], (F,), dev)
+        direct_bn = acc_beta and acc_gamma
+        world = _group_world(group)
         call('xps_bn_bwd_reduce_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(drop_mask),
-             drop_scale, int(relu), _ptr(sums), rows, F, _ptr(ws), nbytes, _stream())
-        if _group_world(group) > 1:             # SyncBN: the dy formula needs the global sums, the
-            local = sums.clone()                # parameter gradients the local ones (averaged with the rest later)
+             drop_scale, int(relu), _ptr(sums), _ptr(g_beta) if direct_bn else None, _ptr(g_gamma) if direct_bn else None,
+             rows, F, _ptr(ws), nbytes, _stream())
+        dbeta = dgamma = None
+        if not direct_bn:
+            local = sums.clone() if world > 1 else sums
+            dbeta, dgamma = local[:F], local[F:]
+        if world > 1:                           # SyncBN: the dy formula needs the global sums
             _dist_sum_(sums, group)
             # every gradient downstream of this layer is enqueued by now: a data-parallel optimiser may start
             # reducing them (AFTER the statistics exchange above, so that it never queues behind a large one)
             for hook in list(POST_SYNCBN_HOOKS):
                 hook()
-        else:
-            local = sums
-        dbeta, dgamma = local[:F], local[F:]
         dy = torch.empty_like(y)
         call('xps_bn_bwd_apply_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma),
              _ptr(drop_mask), drop_scale, int(relu), _ptr(sums), count, _ptr(dy), rows, F, _stream())
         # dW2[f][kk*C + c] = sum_m dy[m][f] * window[m][kk*C + c], m = (b, t'); conv-bias gradient = the
         # column sums of dy, produced by the same launch
-        dconv_b = torch.empty(F, dtype=_f32, device=dev)
+        dconv_b, acc_cb, r_cb = _grad_target(ctx.conv_b, (F,), dev) if ctx.conv_b is not None else (None, False, None)
+        if dconv_b is None:
+            dconv_b = r_cb = torch.empty(F, dtype=_f32, device=dev)
         dw2 = torch.empty(F, k * Cin, dtype=_f32, device=dev)
         # contraction rows in (t', b) order: dy is then a plain contiguous matrix and the window rows of x form
         # groups of B rows (stride T*C) per t' (stride s*C) -- k-tiles never straddle a group when 16 | B, which
         # keeps both operands on the unguarded load path
         gemm_tn_grouped([tn_problem(dy, x, dw2, F, k * Cin, rows, ra=rowmap(F),
-                                    rb=rowmap(T * Cin, rpg=B, gs=stride * Cin), colsum_out=dconv_b)], dev)
+                                    rb=rowmap(T * Cin, rpg=B, gs=stride * Cin), colsum_out=dconv_b,
+                                    accumulate_colsum=acc_cb)], dev)
         gw, acc_w, _ = _grad_target(ctx.conv_w, (F, Cin, k), dev)
         if acc_w:                               # un-permute and accumulate in one pass, straight into .grad
             gw.add_(dw2.view(F, k, Cin).permute(0, 2, 1))
             dconv_w = None
         else:
             dconv_w = dw2.view(F, k, Cin).permute(0, 2, 1).contiguous()
-        return (None, dconv_w, dconv_b, dgamma, dbeta) + (None,) * 12
+        return (None, dconv_w, r_cb, dgamma, dbeta) + (None,) * 12
 
 
 # --------------------------------------------------------------------------- #
@@ -842,6 +856,14 @@ def grad_sumsq(flat_grad, out=None):
     ws = _ws(nbytes, flat_grad.device)
     call('xps_sumsq_f32', _ptr(flat_grad), flat_grad.numel(), _ptr(out), _ptr(ws), nbytes, _stream())
     return out
+
+
+def clip_adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+    """global-norm partials + fused clip / AdamW (the final fold of the norm happens inside the update kernel)."""
+    nbytes = lib().xps_sumsq_f32_workspace(g.numel())
+    ws = _ws(nbytes, g.device)
+    call('xps_clip_adamw_f32', _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq), float(max_norm or 0.0),
+         float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _ptr(ws), nbytes, _stream())
 
 
 def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step):

@@ -133,9 +133,8 @@ class FlatAdamW:
             if not self._avg:
                 self.flat_g.mul_(1.0 / world)
         self.step_count += 1
-        XF.grad_sumsq(self.flat_g, out=self.sumsq)
-        XF.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, self.max_norm or 0.0,
-                      self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count)
+        XF.clip_adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.sumsq, self.max_norm or 0.0,
+                           self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count)
 
     def grad_norm(self):
         """Global gradient norm (before clipping) of the last step: device scalar."""

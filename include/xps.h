@@ -92,7 +92,7 @@ int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra, const float* B, const 
 typedef struct xps_tn_problem {
     const float* A; const float* B; float* C; float* colsum_a;
     xps_rowmap ra, rb, rc;
-    int32_t M, N, K, accumulate;
+    int32_t M, N, K, accumulate;      /* bit 0: C and colsum_a accumulate; bit 1: colsum_a alone accumulates */
 } xps_tn_problem;
 size_t xps_gemm_tn_grouped_f32_workspace(const xps_tn_problem* probs, int n);
 int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void* workspace, size_t workspace_bytes,
@@ -160,11 +160,12 @@ int xps_bn_apply_eval_f32(const float* y, const float* running_mean, const float
                           const float* gamma, const float* beta, float* out,
                           int64_t rows, int F, int relu, void* stream);
 /* backward: pass 1 = g = dout * mask * relu'(out); sums[0:F] = sum g, sums[F:2F] = sum g*xhat
- *           (caller all-reduces sums under DP); pass 2 = dy                                   */
+ *           (caller all-reduces sums under DP); dbeta_acc / dgamma_acc (optional, [F]): the LOCAL sums are
+ *           also added into them (parameter gradients straight into their buffers); pass 2 = dy */
 size_t xps_bn_bwd_workspace(int64_t rows, int F);
 int xps_bn_bwd_reduce_f32(const float* dout, const float* out, const float* y, const float* mean,
                           const float* rstd, const float* drop_mask, float drop_scale, int relu,
-                          float* sums, int64_t rows, int F,
+                          float* sums, float* dbeta_acc, float* dgamma_acc, int64_t rows, int F,
                           void* workspace, size_t workspace_bytes, void* stream);
 int xps_bn_bwd_apply_f32(const float* dout, const float* out, const float* y, const float* mean,
                          const float* rstd, const float* gamma, const float* drop_mask,
@@ -253,6 +254,11 @@ int xps_sumsq_f32(const float* g, int64_t n, float* sumsq, void* workspace, size
 int xps_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   void* stream);
+/* the two above in TWO launches instead of three: gradient-norm partials, then clip + AdamW with the final fold of
+ * the partials inside (sumsq[0], optional, receives the total = squared pre-clip norm); workspace as xps_sumsq_f32 */
+int xps_clip_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, float* sumsq, float max_norm, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int step, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Alignment (alignment/alignment_utils.py:42-61 cnd_avg; AlignCCA.py:235-285;   */
