@@ -54,6 +54,7 @@ SIGNATURES = {
     'xps_gru_seq_bwd_f32_workspace': (_sz, [_i, _i, _i, _i]),
     'xps_gru_seq_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'xps_transpose_f32': (_i, [_vp, _vp, _i, _i, _vp]),
+    'xps_transpose_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xps_bn_finalize_f32': (_i, [_vp, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp]),
     'xps_bn_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
     'xps_bn_apply_eval_f32': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -939,6 +939,24 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
     }
 }
 
+// up to 4 equally shaped matrices in one launch (blockIdx.z selects the matrix)
+struct TransposeBatch { const float* src[4]; float* dst[4]; };
+__global__ void transpose_batched_kernel(TransposeBatch tb, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const float* __restrict__ src = tb.src[blockIdx.z];
+    float* __restrict__ dst = tb.dst[blockIdx.z];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int c = bx + i, r = by + threadIdx.x;
+        if (c < cols && r < rows) dst[(long long)c * rows + r] = tile[threadIdx.x][i];
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // XPS_GRU_STEP_PATH=0 forces the streaming persistent kernels for H > 128 (A/B comparisons)
@@ -1099,6 +1117,21 @@ extern "C" int xps_transpose_f32(const float* src, float* dst, int rows, int col
     if (rows == 0 || cols == 0) return XPS_OK;
     dim3 grid(cdiv(cols, 32), cdiv(rows, 32));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, src, dst, rows, cols);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_transpose_batched_f32(const float* const* src, float* const* dst, int n, int rows, int cols, void* stream) {
+    XPS_CHECK_ARG(src && dst && n >= 1 && n <= 4 && rows >= 0 && cols >= 0, "bad argument (1..4 matrices)");
+    if (rows == 0 || cols == 0) return XPS_OK;
+    TransposeBatch tb;
+    for (int i = 0; i < 4; ++i) {
+        const int j = i < n ? i : 0;
+        XPS_CHECK_ARG(src[j] && dst[j], "null matrix pointer");
+        tb.src[i] = src[j]; tb.dst[i] = dst[j];
+    }
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), n), dim3(32, 8), 0, (hipStream_t)stream,
+                       tb, rows, cols);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

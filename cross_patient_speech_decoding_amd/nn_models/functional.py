@@ -251,7 +251,11 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
         dhn = dhn.contiguous()
     if dy is None and dhn is None:
         dhn = torch.zeros(ndir, B, H, dtype=_f32, device=dev)
-    w_t = [transpose(w, 3 * H, H) for w in w_hh]
+    if len(w_hh) > 1:           # both directions in one launch
+        w_t = [torch.empty(H, 3 * H, dtype=_f32, device=dev) for _ in w_hh]
+        call('xps_transpose_batched_f32', _ptr_array(w_hh), _ptr_array(w_t), len(w_hh), 3 * H, H, _stream())
+    else:
+        w_t = [transpose(w, 3 * H, H) for w in w_hh]
     dgi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
     dghn = torch.empty(ndir, T, B, H, dtype=_f32, device=dev)
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None

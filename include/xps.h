@@ -139,6 +139,8 @@ int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, c
                         int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
 
 int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
+/* 1..4 equally shaped matrices in one launch (host arrays of device pointers): both directions' W_hh^T */
+int xps_transpose_batched_f32(const float* const* src, float* const* dst, int n, int rows, int cols, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* TemporalConv = Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                    */
