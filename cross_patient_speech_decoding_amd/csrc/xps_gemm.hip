@@ -23,7 +23,7 @@ namespace {
 // C (+)= A B (+ A2 B2) + bias.  MI = 1: 64 x 128 tiles (twice the blocks, for grids that would not fill
 // the chip with 128 x 128 tiles);  A2/B2: an optional second operand pair with the same row maps (the two
 // directions of a bidirectional layer summed in registers instead of a second accumulate pass).
-template <bool AK, bool BK, int MI>
+template <bool AK, bool BK, int MI, bool EDGE = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
     const float* __restrict__ A2, const float* __restrict__ B2, int K2,
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
-    gemm_accumulate<AK, BK, MI>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
-    if (A2) gemm_accumulate<AK, BK, MI>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
+    gemm_accumulate<AK, BK, MI, EDGE>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
+    if (A2) gemm_accumulate<AK, BK, MI, EDGE>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
     gemm_store<MI>(acc, C + (long long)z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
@@ -129,7 +129,7 @@ struct NtMulti {
     const float* bias[4];
     float* C[4];
 };
-template <int MI>
+template <int MI, bool EDGE = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int nprob,
     int vecA, int vecB) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
-    gemm_accumulate<true, true, MI>(acc, nocs, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, As, Bs);
+    gemm_accumulate<true, true, MI, EDGE>(acc, nocs, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, As, Bs);
     gemm_store<MI>(acc, pm.C[z], rc, pm.bias[z], M, N, m0, n0, 0);
 }
 
@@ -168,6 +168,7 @@ struct TnGroup {
     long long total_out;      // sum of M * (N + has_colsum)
 };
 
+template <bool EDGE>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     f32x16 acc[2][2];
     zero_acc<2>(acc);
     float csum = 0.f;
-    gemm_accumulate<false, false, 2>(acc, csum, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
+    gemm_accumulate<false, false, 2, EDGE>(acc, csum, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
                                      kbeg, kend, P.vecA, P.vecB, As, Bs);
     gemm_store<2>(acc, slab, rs, nullptr, P.M, P.N, tm * BM, tn * BN, 0);
     if (cs) {                                   // fold the two k-groups of the column sums through LDS
@@ -310,12 +311,20 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
     }
     if (use_small_tiles(M, N)) {
         dim3 grid(cdiv(N, BN) * cdiv(M, 64));
-        hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
-                           M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+        if (M % 64 || N % BN)
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1, true>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
+                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
+                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
     } else {
         dim3 grid(cdiv(N, BN) * cdiv(M, 128));
-        hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
-                           M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+        if (M % 128 || N % BN)
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2, true>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
+                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
+                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -367,11 +376,19 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
     }
     const int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
     if (use_small_tiles(M, N * nprob)) {
-        hipLaunchKernelGGL((gemm_nt_multi_kernel<1>), dim3(cdiv(N, BN) * cdiv(M, 64) * nprob), dim3(256), 0, (hipStream_t)stream,
-                           A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
+        if (M % 64 || N % BN)
+            hipLaunchKernelGGL((gemm_nt_multi_kernel<1, true>), dim3(cdiv(N, BN) * cdiv(M, 64) * nprob), dim3(256), 0,
+                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
+        else
+            hipLaunchKernelGGL((gemm_nt_multi_kernel<1>), dim3(cdiv(N, BN) * cdiv(M, 64) * nprob), dim3(256), 0,
+                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
     } else {
-        hipLaunchKernelGGL((gemm_nt_multi_kernel<2>), dim3(cdiv(N, BN) * cdiv(M, 128) * nprob), dim3(256), 0, (hipStream_t)stream,
-                           A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
+        if (M % 128 || N % BN)
+            hipLaunchKernelGGL((gemm_nt_multi_kernel<2, true>), dim3(cdiv(N, BN) * cdiv(M, 128) * nprob), dim3(256), 0,
+                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
+        else
+            hipLaunchKernelGGL((gemm_nt_multi_kernel<2>), dim3(cdiv(N, BN) * cdiv(M, 128) * nprob), dim3(256), 0,
+                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
     }
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -496,7 +513,12 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
         xps_set_error("xps_gemm_tn_grouped_f32: workspace too small or misaligned");
         return XPS_E_WORKSPACE;
     }
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    bool edge = false;
+    for (int i = 0; i < n; ++i) edge = edge || (probs[i].M % BM) || (probs[i].N % BN);
+    if (edge)
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel<true>, dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    else
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel<false>, dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     XPS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT)), dim3(256), 0, (hipStream_t)stream, g,
                        (const float*)workspace);

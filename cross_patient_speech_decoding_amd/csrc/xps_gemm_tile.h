@@ -261,7 +261,9 @@ __device__ inline void gemm_pipeline(f32x16 (&acc)[MI][2], float& csum, const bo
 
 // acc += A(m0.., k) B(k, n0..) over k in [kbeg, kend) for one (64*MI) x 128 output tile.  Interior, aligned
 // tiles run the unguarded pipeline over all full k-tiles and the guarded one only over a ragged k tail.
-template <bool AK, bool BK, int MI>
+// EDGE: also instantiate the predicated pipeline for partial tiles (kernels launched for problems whose M / N are
+// not tile multiples); the interior-only instantiation stays as compact as it was (it lost 3-9 % with the extra code).
+template <bool AK, bool BK, int MI, bool EDGE = false>
 __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
                                        const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                        int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
@@ -281,7 +283,7 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float& csum, const 
         gemm_pipeline<AK, BK, MI, 1>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
         if (kfull < kend)
             gemm_pipeline<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
-    } else if (both_fast && !both_full) {
+    } else if (EDGE && both_fast && !both_full) {
         gemm_pipeline<AK, BK, MI, 2>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, As, Bs);
         if (kfull < kend)
             gemm_pipeline<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, As, Bs);
