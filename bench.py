@@ -101,7 +101,32 @@ def _event_time(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def time_dominant_kernel(model, c):
+def capture_dominant_launch(step_fn):
+    """Run ONE more training step with the grouped weight-gradient entry point wrapped: returns the problem list of
+    its largest launch (by FLOPs) and the tensors that keep its operands alive -- the step's own operands."""
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    seen = []
+    orig_group, orig_launch = XF.gemm_tn_grouped, XF._launch_weight_grads
+    holder = {'tensors': ()}
+
+    def launch(fn, device, tensors, direct):
+        holder['tensors'] = tensors
+        return orig_launch(fn, device, tensors, direct)
+
+    def group(problems, device):
+        fl = sum(2.0 * q.M * q.N * q.K for q in problems)
+        seen.append((fl, list(problems), holder['tensors']))
+        return orig_group(problems, device)
+    XF.gemm_tn_grouped, XF._launch_weight_grads = group, launch
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        XF.gemm_tn_grouped, XF._launch_weight_grads = orig_group, orig_launch
+    return max(seen, key=lambda t: t[0]) if seen else None
+
+
+def time_dominant_kernel(model, c, captured=None):
     """Roofline of the kernel with the largest share of the step (profiles/round1/r1c_*): the fp32-MFMA
     GEMM tile kernel, measured on its largest single launch = the grouped weight-gradient GEMM of encoder
     layer 1 (6 problems, K = T'*B rows).  Algorithmic FLOPs = sum 2*M*N*K over the group.  The fused GRU
@@ -129,8 +154,16 @@ def time_dominant_kernel(model, c):
                                        rc=XF.rowmap(H), colsum_out=db_hh[2 * H:]))
             probs.append(XF.tn_problem(dgi[d], x, dw_ih, 3 * H, In, K, colsum_out=db_ih))
         XF.gemm_tn_grouped(probs, dev)
-    dur = _event_time(launch)
+    dur_rand = _event_time(launch)
     flops = 2 * (2 * K * (3 * H * H + 3 * H * In))
+    dur = dur_rand
+    operands = 'random normal operands of the step\'s shapes'
+    if captured is not None and abs(captured[0] - flops) < 1e-6 * flops:
+        # the SAME launch on the operands of a real backward pass (gradients and dropout-masked activations): the
+        # matrix pipe draws less power on them than on dense random data and holds higher clocks
+        probs_real = captured[1]
+        dur = _event_time(lambda: XF.gemm_tn_grouped(probs_real, dev))
+        operands = 'operands captured from a training step'
     ach = flops / dur / 1e12
     # second: the fused GRU recurrence of one encoder layer (both directions, one launch)
     rnn = model.encoder.rnn
@@ -151,7 +184,8 @@ def time_dominant_kernel(model, c):
                                        'gradients, 6 problems in one launch, incl. its reduce pass)',
             'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-            'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops,
+            'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops, 'operands': operands,
+            'random_operands': {'achieved': round(flops / dur_rand / 1e12, 3), 'launch_us': round(dur_rand * 1e6, 1)},
             'also': {'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions)',
                      'achieved': round(fl_gru / dur_gru / 1e12, 3), 'frac': round(fl_gru / dur_gru / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                      'launch_us': round(dur_gru * 1e6, 1), 'flops_per_launch': fl_gru}}
@@ -248,7 +282,7 @@ def main():
             'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
         }
         if not explore:
-            out['roofline'] = time_dominant_kernel(model, c)
+            out['roofline'] = time_dominant_kernel(model, c, capture_dominant_launch(step))
         else:
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:
