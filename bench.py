@@ -282,7 +282,8 @@ def main():
             'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
         }
         if not explore:
-            out['roofline'] = time_dominant_kernel(model, c, capture_dominant_launch(step))
+            # the capture runs one more training step: single process only (under DP it would issue collectives alone)
+            out['roofline'] = time_dominant_kernel(model, c, capture_dominant_launch(step) if world == 1 else None)
         else:
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:
