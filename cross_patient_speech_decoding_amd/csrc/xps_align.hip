@@ -52,12 +52,32 @@ __global__ __launch_bounds__(256) void colsum64_stage1(const T* __restrict__ X, 
         part[(long long)blockIdx.y * d + c] = (sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l]);
     }
 }
-__global__ void colsum64_stage2(const double* __restrict__ part, int nparts, int d, double* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
+// one 1024-thread block per 64 columns: sixteen partial-row groups with 8 loads in flight each, folded in a fixed order
+// (a single thread walking hundreds of partials serially took 76 us)
+__global__ __launch_bounds__(1024) void colsum64_stage2(const double* __restrict__ part, int nparts, int d, double* __restrict__ out) {
+    __shared__ double sh[16][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     double a = 0.0;
-    for (int i = 0; i < nparts; ++i) a += part[(long long)i * d + c];
-    out[c] = a;
+    if (c < d) {
+        int i = q;
+        for (; i + 7 * 16 < nparts; i += 8 * 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)(i + 16 * u) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; i < nparts; i += 16) a += part[(long long)i * d + c];
+    }
+    sh[q][l] = a;
+    __syncthreads();
+    if (q == 0 && c < d) {
+        a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += sh[k][l];
+        out[c] = a;
+    }
 }
 
 // ------------------------------------------------------------- f64 MFMA GEMM ----
@@ -566,7 +586,7 @@ extern "C" int xps_colsum_f64(const void* X, int is_f32, int64_t ldx, int64_t n,
                                (const double*)X, (long long)ldx, (long long)n, d, part);
         XPS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(colsum64_stage2, dim3(cdiv(d, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, d, out);
+    hipLaunchKernelGGL(colsum64_stage2, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, part, nparts, d, out);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
