@@ -59,6 +59,59 @@ def process_aligner(X, y, y_align, pool_data, algner, n_components=0.95):
     return torch.Tensor(X_pool), y_pool, tar_dr
 
 
+def process_aligner_sharded(X, y, y_align, pool_data, algner, n_components=0.95, group=None):
+    """``process_aligner`` with the PATIENTS sharded over the ranks of ``group`` (P patients <-> P GPUs).
+
+    Rank 0 owns the target, pooled patient i (0-based) is owned by rank (i + 1) % world.  Every owner reduces its
+    patients with PCA on its own GPU; the target's latent trials are broadcast once (2048 x 200 x d floats: 49 MB at
+    d = 30); every owner fits / applies its CCA maps; the aligned trials of each patient are broadcast from their owner,
+    so all ranks end with the pooled training set of the single-process function (same order, same values: every
+    decomposition is deterministic).  Exchanges: 1 + P broadcasts of (N, T, d) float32 blocks and their shapes; no other
+    collective (the eigen-decompositions are tiny and never split).  Returns what ``process_aligner`` returns; the
+    fitted target PCA lives on every rank (each fits it: 9 ms, cheaper than shipping it)."""
+    import torch.distributed as dist
+    if group is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return process_aligner(X, y, y_align, pool_data, algner, n_components)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    Xn = _np(X)
+    if y_align is None:
+        y_align = y
+    tar_dr = PCA(n_components=n_components)
+    z = tar_dr.fit_transform(Xn.reshape(-1, Xn.shape[-1]))
+    X_tar = z.reshape(Xn.shape[0], -1, z.shape[-1])
+    # the target PCA is deterministic, so every rank already holds the same X_tar: no broadcast needed for it
+    aligned = []
+    for i, (x, _, ya_c) in enumerate(pool_data):
+        owner = (i + 1) % world
+        src = dist.get_global_rank(group, owner) if hasattr(dist, 'get_global_rank') else owner
+        if rank == owner:
+            xn = _np(x)
+            zz = PCA(n_components=n_components).fit_transform(xn.reshape(-1, xn.shape[-1]))
+            x_dr = zz.reshape(xn.shape[0], -1, zz.shape[-1])
+            al = algner()
+            al.fit(X_tar, x_dr, _np(y_align), _np(ya_c))
+            out = np.ascontiguousarray(al.transform(x_dr), dtype=np.float32)
+            shape = torch.tensor(out.shape, dtype=torch.int64, device=dev)
+        else:
+            shape = torch.zeros(3, dtype=torch.int64, device=dev)
+        dist.broadcast(shape, src=src, group=group)
+        buf = torch.from_numpy(out).to(dev) if rank == owner else torch.empty(tuple(int(v) for v in shape), dtype=torch.float32,
+                                                                             device=dev)
+        dist.broadcast(buf, src=src, group=group)
+        aligned.append(buf.cpu().numpy())
+    X_pool = np.vstack([X_tar] + aligned)
+    ys = [_np(y)] + [_np(yy) for _, yy, _ in pool_data]
+    try:
+        y_pool = np.hstack(ys)
+    except ValueError:
+        y_pool = np.vstack(ys)
+    y_pool = torch.Tensor(y_pool).long()
+    if y_pool.dim() > 1 and y_pool.shape[1] == 1:
+        y_pool = y_pool.squeeze(1)
+    return torch.Tensor(X_pool), y_pool, tar_dr
+
+
 def process_aligner_multiview(X, y, y_align, pool_data, algner, n_components=0.95):
     """Multiview (MCCA / joint-PCA) counterpart: PCA per patient, ONE ``algner()`` fitted on all
     views ([target] + pooled; fit(Xs, ys) / transform(X, idx) API), every view mapped into the shared
@@ -186,14 +239,16 @@ class AlignedMicroDataModule(_FoldModule):
     align_before_split = False
 
     def __init__(self, data, labels, align_labels, pool_data, algner, batch_size=128, folds=20, val_size=0.2,
-                 augmentations=None, data_path=None, save_folds=False, multiview=False):
+                 augmentations=None, data_path=None, save_folds=False, multiview=False, process_group=None):
         super().__init__(data, labels, batch_size, folds, val_size, augmentations, data_path, save_folds)
         self.align_labels, self.pool_data, self.algner = align_labels, pool_data, algner
         self.multiview = multiview
+        self.process_group = process_group           # data parallel: the pooled patients are aligned one per rank
 
     def _align(self, X, y, y_align, pool):
-        fn = process_aligner_multiview if self.multiview else process_aligner
-        return fn(X, y, y_align, pool, self.algner)
+        if self.multiview:
+            return process_aligner_multiview(X, y, y_align, pool, self.algner)
+        return process_aligner_sharded(X, y, y_align, pool, self.algner, group=self.process_group)
 
     def _project(self, dim_red, X):
         shp = X.shape

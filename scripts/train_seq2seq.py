@@ -79,6 +79,7 @@ def seq2seq_decoding():
     fold_data_path = os.path.join(base, 'datamodules', pt, context_prefix)
     if pool_train:
         dm = AlignedMicroValDataModule(data, align_labels, align_labels, pool_data, AlignCCA, batch_size=batch_size,
+                                       process_group=dist.group.WORLD if dist.is_initialized() else None,
                                        folds=n_folds, val_size=val_size, augmentations=augmentations,
                                        data_path=fold_data_path)
     else:

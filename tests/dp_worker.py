@@ -49,10 +49,31 @@ def hip_step(rank, world, X, y, group):
     return (opt.flat_g.cpu().numpy(), opt.flat_p.cpu().numpy(), float(gnorm), m.temporal_conv.bn.running_var.cpu().numpy())
 
 
+def _patients():
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    return [make_patient(p, 90 - 6 * p, T=40, C=(14, 12, 10, 16)[p], n_cond=10) for p in range(4)]
+
+
+def sharded_alignment(group):
+    """process_aligner_sharded over `group` (None: the single-process process_aligner)."""
+    from cross_patient_speech_decoding_amd.alignment import AlignCCA
+    from cross_patient_speech_decoding_amd.nn_models.data_utils.datamodules import process_aligner_sharded
+    pats = _patients()
+    (Xt, yt), pool = pats[0], [(torch.from_numpy(x), torch.from_numpy(y - 1), torch.from_numpy(y - 1)) for x, y in pats[1:]]
+    Xp, yp, tar = process_aligner_sharded(torch.from_numpy(Xt), torch.from_numpy(yt - 1), torch.from_numpy(yt - 1), pool, AlignCCA,
+                                          group=group)
+    return Xp.numpy(), yp.numpy(), int(tar.n_components_)
+
+
 def worker(rank, world, device, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     X, y = data()
-    if device == 'cuda':
+    if device == 'align':
+        torch.cuda.set_device(0)
+        res = sharded_alignment(dist.group.WORLD)
+        if rank == 1:                       # a rank that does NOT own the target
+            q.put(res)
+    elif device == 'cuda':
         torch.cuda.set_device(0)
         res = hip_step(rank, world, X, y, dist.group.WORLD)
         if rank == 0:
@@ -100,6 +121,11 @@ def main():
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0, p.exitcode
+    if a.device == 'align':
+        Xs, ys, ks = res
+        X1, y1, k1 = sharded_alignment(None)
+        assert ks == k1 and Xs.shape == X1.shape and (ys == y1).all()
+        assert (Xs == X1).all(), float(abs(Xs - X1).max())          # deterministic decompositions: identical pooled set
     if a.device == 'cuda':
         X, y = data()
         g1, p1, n1, rv1 = [torch.as_tensor(v) if not isinstance(v, float) else v for v in hip_step(0, 1, X, y, None)]

@@ -128,6 +128,16 @@ def test_data_parallel_two_ranks_equal_single_process():
     assert 'DP_OK' in out.stdout
 
 
+def test_patient_sharded_alignment_equals_single_process():
+    """SURVEY 8e, alignment: patients sharded over ranks (PCA + CCA on the owner's GPU, aligned trials broadcast):
+    the pooled training set of 3 ranks is identical to the single-process one."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29523', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', '3', '--device', 'align'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert 'DP_OK' in out.stdout
+
+
 def test_train_seq2seq_cli_end_to_end(tmp_path):
     """The counterpart of scripts/train_seq2seq.py: pooled + CCA-aligned k-fold training on synthetic patients."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train_seq2seq.py'), '-pt', 'SYN', '-p', 'True',
