@@ -1,0 +1,1 @@
+"""Synthetic-data helpers shared by the benchmarks, the CLI and the tests."""
