@@ -74,6 +74,7 @@ class FlatAdamW:
         # small latency-critical exchange is never queued behind the large one.  XPS_DP_OVERLAP=0 disables.
         self._split = None
         self._early = None
+        self._comm_stream = None
         world, _ = _world(group)
         # RCCL averages in the collective (no extra pass over the buffer); gloo (CPU tests) sums, then one scale
         self._avg = world > 1 and dist.get_backend(group) == 'nccl'
@@ -92,7 +93,8 @@ class FlatAdamW:
 
     def _reduce_tail_async(self):
         """Hook (autograd thread, during backward): all-reduce flat_g[split:] without blocking the main stream.
-        Issued from the side stream that carries the weight-gradient GEMMs so that it waits for them."""
+        Issued from an ordinary torch stream that first waits for the main stream and for the side stream carrying
+        the weight-gradient GEMMs; ``step()`` waits for the returned work handle."""
         if self._early is not None:
             return
         # only valid while every gradient of the tail lives in the flat buffer (direct accumulation)
@@ -100,14 +102,24 @@ class FlatAdamW:
             if p.grad is None or p.grad.data_ptr() != view.data_ptr():
                 return
         dev = self.flat_g.device
-        side = XF._side_streams.get(dev.index if dev.index is not None else torch.cuda.current_device())
-        tail = self.flat_g[self._split:]
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream(dev))       # gradients written on the main stream too
-            with torch.cuda.stream(side):
-                self._early = dist.all_reduce(tail, op=self._op, group=self.group, async_op=True)
-        else:
-            self._early = dist.all_reduce(tail, op=self._op, group=self.group, async_op=True)
+        try:
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=idx)       # an ordinary torch stream for the collective
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream(idx))              # gradients written on the main stream ...
+            side = XF._side_streams.get(idx)
+            if side is not None:
+                cs.wait_stream(side)                                    # ... and by the weight-gradient GEMMs on the side stream
+            with torch.cuda.stream(cs):
+                self._early = dist.all_reduce(self.flat_g[self._split:], op=self._op, group=self.group, async_op=True)
+        except Exception as e:                                          # never fatal: step() reduces everything instead
+            import warnings
+            warnings.warn(f'overlapped gradient all-reduce disabled ({type(e).__name__}: {e})')
+            self._early = None
+            self._split = None
+            self._avg, self._op = False, dist.ReduceOp.SUM              # most conservative collective from here on
+            XF.POST_SYNCBN_HOOKS[:] = [h for h in XF.POST_SYNCBN_HOOKS if getattr(h, '__self__', None) is not self]
 
     @torch.no_grad()
     def step(self):
@@ -125,9 +137,9 @@ class FlatAdamW:
                 p.grad = view
         if world > 1:
             if self._early is not None:                    # the tail went out during backward: only the head is left
-                dist.all_reduce(self.flat_g[:self._split], op=self._op, group=self.group)
-                self._early.wait()
+                self._early.wait()                         # (current stream waits for the collective)
                 self._early = None
+                dist.all_reduce(self.flat_g[:self._split], op=self._op, group=self.group)
             else:
                 dist.all_reduce(self.flat_g, op=self._op, group=self.group)
             if not self._avg:
