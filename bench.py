@@ -81,6 +81,7 @@ def cpu_baseline(c, budget_s=20.0):
         train_step(m, opt, X, y, coins=[True, False, True])
         n += 1
         el = time.perf_counter() - t0
+    gc.enable()
         if el > budget_s or n >= 200:
             break
     return {'value': round(256 * n / el, 1), 'unit': 'trials/s', 'cores': threads, 'kind': 'port',
@@ -257,6 +258,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()                                 # no collector pauses inside the timed region (they gate every rank under DP)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
