@@ -81,7 +81,6 @@ def cpu_baseline(c, budget_s=20.0):
         train_step(m, opt, X, y, coins=[True, False, True])
         n += 1
         el = time.perf_counter() - t0
-    gc.enable()
         if el > budget_s or n >= 200:
             break
     return {'value': round(256 * n / el, 1), 'unit': 'trials/s', 'cores': threads, 'kind': 'port',
@@ -269,6 +268,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
