@@ -259,7 +259,8 @@ def main():
     torch.cuda.synchronize()
     import gc
     gc.collect()
-    gc.disable()                                 # no collector pauses inside the timed region (they gate every rank under DP)
+    if os.environ.get('XPS_BENCH_GC', '0') != '1':
+        gc.disable()                             # no collector pauses inside the timed region (they gate every rank under DP)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
