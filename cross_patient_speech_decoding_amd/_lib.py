@@ -92,6 +92,8 @@ SIGNATURES = {
     'xps_jacobi_small_supported': (_i, [_i, _i, _i]),
     'xps_jacobi_small_f64': (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     'xps_apply_f64': (_i, [_vp, _i, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i, _i, _vp]),
+    'xps_process_hg_f64_workspace': (_sz, [_i, _i, _i]),
+    'xps_process_hg_f64': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xps_dgemm_small': (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp]),
 }
 

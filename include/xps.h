@@ -306,6 +306,16 @@ int xps_jacobi_small_supported(int m, int n, int want_v);
 int xps_jacobi_small_f64(double* W, int64_t ldw, int64_t stride_w, double* V, int64_t ldv, int64_t stride_v,
                          int m, int n, int batch, int max_sweeps, double tol, int32_t* sweeps_done, double* off,
                          void* stream);
+/* Per-bin high-gamma features of the realtime pipeline (realtime_sim/realtime_processing.py:10-164 process_HG):
+ * common average reference over the `good` channels (do_car) -> `bands` filters in scipy.signal.lfilter's direct-form-II-
+ * transposed arithmetic (b, a: [bands][taps], normalised by a[0] inside; a == NULL: FIR) with the carried state
+ * zi [bands][C][taps-1] updated in place (NULL: zero state) -> RMS over (time, bands) per channel in numpy's summation order.
+ * data [C][Tn] float64.  Optional outputs: car_out [C][Tn], filtered [C][Tn][bands], power [C] (filtered and power are
+ * exclusive: the power pass squares its copy in place; without `filtered` the copy lives in the workspace).            */
+size_t xps_process_hg_f64_workspace(int C, int Tn, int bands);
+int xps_process_hg_f64(const double* data, int C, int Tn, const uint8_t* good, const double* b, const double* a,
+                       int bands, int taps, double* zi, int do_car, double* car_out, double* filtered,
+                       double* power, void* workspace, size_t workspace_bytes, void* stream);
 /* Y[r][:] = (X[r][:] - mean) @ Wt   X: n x d_in (float32 or float64), W: d_in x d_out float64,
  * Y float64 or float32.  Batched transform apply of every aligner.              */
 int xps_apply_f64(const void* X, int x_is_f32, int64_t ldx, const double* mean, const double* W,
