@@ -108,6 +108,45 @@ def test_seeded_larger_batch_vs_oracle():
     assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4
 
 
+def test_full_bench_size_step_vs_oracle():
+    """The bench workload itself (cfg 2: 2048 trials x 200 samples x 64 channels, H = 128): eval logits / argmax, training
+    loss and the gradient of every parameter of one full-batch step against the CPU oracle (no dropout: deterministic)."""
+    from oracle.seq2seq_oracle import Seq2SeqOracle
+    torch.set_num_threads(16)
+    cfg = dict(in_channels=64, n_filters=100, hidden_size=128, n_enc_layers=2, n_dec_layers=1, kernel_size=10,
+               stride=10, activation=False)
+    orc = Seq2SeqOracle(64, 100, 128, 9, 2, 1, 10, 10, 0, 0.0, 0.0, activation=False)
+    orc.load_state_dict(weights_from_seed(orc.state_dict(), 21))
+    m = build_hip(cfg, 21)
+    rng = np.random.default_rng(22)
+    B = 2048
+    x = torch.from_numpy(rng.standard_normal((B, 200, 64)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 9, (B, 3)))
+    orc.eval(); m.eval()
+    with torch.no_grad():
+        ref = orc(x, y, teacher_forcing_ratio=0)
+        out = m(x.cuda(), y.cuda(), teacher_forcing_ratio=0)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4
+    assert torch.equal(out.argmax(-1).cpu(), ref.argmax(-1))                  # all 6144 argmax indices identical
+    orc.train(); m.train()
+    coins = [True, False, True]
+    ref = orc(x, y, coins=coins)
+    loss_ref = torch.nn.functional.cross_entropy(ref.reshape(-1, 9), y.reshape(-1))
+    loss_ref.backward()
+    out = m(x.cuda(), y.cuda(), coins=coins)
+    loss = m.criterion(out.view(-1, 9), y.cuda().view(-1))
+    loss.backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4
+    np.testing.assert_allclose(float(loss.detach()), float(loss_ref.detach()), rtol=1e-5)
+    refs = dict(orc.named_parameters())
+    for k, p in m.named_parameters():
+        if k == NOISE_KEY:
+            continue
+        g_ref = refs[k].grad
+        tol = 1e-4 * max(float(g_ref.abs().max()), 1e-6)
+        assert (p.grad.cpu() - g_ref).abs().max().item() <= tol, k
+
+
 def test_reference_coin_sequence_is_reproduced():
     """Same seed -> the same teacher-forcing coins as the reference's torch.rand(1) draws (models.py:295)."""
     from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
