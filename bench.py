@@ -22,7 +22,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from .._lib import RowMap, TnProblem, call, lib, rowmap
+from .._lib import TnProblem, call, lib, rowmap
 
 _f32 = torch.float32
 

@@ -14,8 +14,7 @@ mode='max')]).fit(model, train_loader, val_loader)``, ``.test(model, loader, ckp
   reference's single-process full-batch step; the global-norm clip is applied to the REDUCED
   gradient, so every rank clips identically.
 """
-import copy
-import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -79,7 +78,6 @@ class FlatAdamW:
         # RCCL averages in the collective (no extra pass over the buffer); gloo (CPU tests) sums, then one scale
         self._avg = world > 1 and dist.get_backend(group) == 'nccl'
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        import os
         if (world > 1 and os.environ.get('XPS_DP_OVERLAP', '1') != '0' and XF.DIRECT_GRAD
                 and hasattr(module, 'temporal_conv')):
             first = {id(p) for p in module.temporal_conv.parameters()}
@@ -196,7 +194,6 @@ class ModelCheckpoint:
             self.best_score = v
             self.best_state = {k: t.detach().clone() for k, t in model.state_dict().items()}
             if self.dirpath is not None and _world()[1] == 0:
-                import os
                 os.makedirs(self.dirpath, exist_ok=True)
                 self.best_model_path = os.path.join(self.dirpath, self.filename + '.ckpt')
                 torch.save({'state_dict': self.best_state}, self.best_model_path)

@@ -7,7 +7,6 @@ with carried state -> RMS); ``process_HG`` runs all three stages in a single lau
 scipy.signal.lfilter's direct-form-II-transposed arithmetic bit for bit (no fused multiply-add), the CAR and RMS stages
 numpy's summation order; the FIR path (scipy evaluates it with np.convolve / BLAS dot products, whose summation order
 is not defined) agrees to rounding.  There is no CPU fallback."""
-import ctypes as C
 
 import numpy as np
 import torch
