@@ -257,7 +257,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     import gc
-    gc.collect()
+    if os.environ.get('XPS_BENCH_COLLECT', '0') == '1':
+        gc.collect()
     if os.environ.get('XPS_BENCH_GC', '0') != '1':
         gc.disable()                             # no collector pauses inside the timed region (they gate every rank under DP)
     t0 = time.perf_counter()
