@@ -15,22 +15,26 @@
 // reads convolution windows of a (trial, time, channel) tensor and writes
 // time-major outputs.
 #include <stdlib.h>
+#include <string.h>
+#include <atomic>
 #include "xps_common.h"
 #include "xps_gemm_tile.h"
 using namespace xps_tile;
+#ifndef XPS_GEMM_DEFAULT_MODE
+#define XPS_GEMM_DEFAULT_MODE 0
+#endif
 namespace {
 
 // C (+)= A B (+ A2 B2) + bias.  MI = 1: 64 x 128 tiles (twice the blocks, for grids that would not fill
 // the chip with 128 x 128 tiles);  A2/B2: an optional second operand pair with the same row maps (the two
 // directions of a bidirectional layer summed in registers instead of a second accumulate pass).
-template <bool AK, bool BK, int MI, bool EDGE = false>
+template <bool AK, bool BK, int MI, bool EDGE = false, bool BF = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
     const float* __restrict__ A2, const float* __restrict__ B2, int K2,
     float* __restrict__ C, RowMap rc, const float* __restrict__ bias,
     int M, int N, int K, int kchunk, long long slab_stride, int accumulate, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
     // 1-D grid, logical order (k-split, m-tile, n-tile): the n-tiles of an A panel run on one XCD
     const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + 64 * MI - 1) / (64 * MI));
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -41,8 +45,8 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
-    gemm_accumulate<AK, BK, MI, EDGE>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
-    if (A2) gemm_accumulate<AK, BK, MI, EDGE>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, As, Bs);
+    gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem);
+    if (A2) gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, mem);
     gemm_store<MI>(acc, C + (long long)z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
@@ -129,12 +133,11 @@ struct NtMulti {
     const float* bias[4];
     float* C[4];
 };
-template <int MI, bool EDGE = false>
+template <int MI, bool EDGE = false, bool BF = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int nprob,
     int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
     // logical order (m-tile, problem, n-tile): all blocks that read one A panel are neighbours on one XCD
     const int tiles_n = (N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
-    gemm_accumulate<true, true, MI, EDGE>(acc, nocs, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, As, Bs);
+    gemm_accumulate_any<true, true, MI, EDGE, BF>(acc, nocs, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, mem);
     gemm_store<MI>(acc, pm.C[z], rc, pm.bias[z], M, N, m0, n0, 0);
 }
 
@@ -168,10 +171,9 @@ struct TnGroup {
     long long total_out;      // sum of M * (N + has_colsum)
 };
 
-template <bool EDGE>
+template <bool EDGE, bool BF = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
     // logical order (problem, k-split, tile): the tiles of one k-chunk are neighbours on one XCD
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
@@ -193,12 +195,12 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     f32x16 acc[2][2];
     zero_acc<2>(acc);
     float csum = 0.f;
-    gemm_accumulate<false, false, 2, EDGE>(acc, csum, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
-                                     kbeg, kend, P.vecA, P.vecB, As, Bs);
+    gemm_accumulate_any<false, false, 2, EDGE, BF>(acc, csum, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
+                                                   kbeg, kend, P.vecA, P.vecB, mem);
     gemm_store<2>(acc, slab, rs, nullptr, P.M, P.N, tm * BM, tn * BN, 0);
     if (cs) {                                   // fold the two k-groups of the column sums through LDS
         const int tid = threadIdx.x;
-        float* red = &Bs[0][0][0];
+        float* red = reinterpret_cast<float*>(&mem);
         __syncthreads();
         red[tid] = csum;
         __syncthreads();
@@ -288,6 +290,20 @@ int tn_splits(int M, int N, int K) {
 }  // namespace
 
 namespace {
+// Product precision of the tile kernels: 0 = fp32 MFMA (exact fp32 fma chains), 1 = bf16 split products (3 bf16 MFMAs
+// per product, ~2^-16 relative product error, fp32 accumulate).  Process-wide; XPS_GEMM_PRECISION=fp32|bf16x3 sets the
+// initial value, xps_set_gemm_precision() changes it (not while launches of another thread are in flight).
+std::atomic<int>& gemm_mode() {
+    static std::atomic<int> mode([] {
+        const char* e = getenv("XPS_GEMM_PRECISION");
+        if (e && (!strcmp(e, "fp32") || !strcmp(e, "f32") || !strcmp(e, "0"))) return 0;
+        if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) return 1;
+        return XPS_GEMM_DEFAULT_MODE;
+    }());
+    return mode;
+}
+inline bool bf_mode() { return gemm_mode().load(std::memory_order_relaxed) == 1; }
+
 // 64-row tiles when 128-row tiles would leave the chip under-filled (< ~2 blocks per CU)
 inline bool use_small_tiles(int M, int N) {
     static const int thr = [] {
@@ -309,23 +325,23 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
                            bias, M, N, K, accumulate, vecB);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    if (use_small_tiles(M, N)) {
+#define XPS_LAUNCH_GEMM(MI_, EDGE_, BF_)                                                                              \
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, MI_, EDGE_, BF_>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, \
+                       bias, M, N, K, kchunk, 0LL, accumulate, vecA, vecB)
+    const bool bf = bf_mode();
+    // the [k][m] A operand of the bf16 pipeline packs two k rows per thread only with 128-row tiles
+    if (use_small_tiles(M, N) && !(bf && !AK)) {
         dim3 grid(cdiv(N, BN) * cdiv(M, 64));
-        if (M % 64 || N % BN)
-            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1, true>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
-                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
-        else
-            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 1>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
-                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+        const bool edge = (M % 64) || (N % BN);
+        if (bf) { if (edge) XPS_LAUNCH_GEMM(1, true, true); else XPS_LAUNCH_GEMM(1, false, true); }
+        else { if (edge) XPS_LAUNCH_GEMM(1, true, false); else XPS_LAUNCH_GEMM(1, false, false); }
     } else {
         dim3 grid(cdiv(N, BN) * cdiv(M, 128));
-        if (M % 128 || N % BN)
-            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2, true>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
-                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
-        else
-            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, 2>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, bias,
-                               M, N, K, kchunk, 0LL, accumulate, vecA, vecB);
+        const bool edge = (M % 128) || (N % BN);
+        if (bf) { if (edge) XPS_LAUNCH_GEMM(2, true, true); else XPS_LAUNCH_GEMM(2, false, true); }
+        else { if (edge) XPS_LAUNCH_GEMM(2, true, false); else XPS_LAUNCH_GEMM(2, false, false); }
     }
+#undef XPS_LAUNCH_GEMM
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 }  // namespace
@@ -375,21 +391,20 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
         vb = vb && map_vec_ok(B[j], rb);
     }
     const int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
+#define XPS_LAUNCH_NTM(MI_, EDGE_, BF_)                                                                                  \
+    hipLaunchKernelGGL((gemm_nt_multi_kernel<MI_, EDGE_, BF_>), dim3(cdiv(N, BN) * cdiv(M, 64 * MI_) * nprob), dim3(256), 0,   \
+                       (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB)
+    const bool bf = bf_mode();
     if (use_small_tiles(M, N * nprob)) {
-        if (M % 64 || N % BN)
-            hipLaunchKernelGGL((gemm_nt_multi_kernel<1, true>), dim3(cdiv(N, BN) * cdiv(M, 64) * nprob), dim3(256), 0,
-                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
-        else
-            hipLaunchKernelGGL((gemm_nt_multi_kernel<1>), dim3(cdiv(N, BN) * cdiv(M, 64) * nprob), dim3(256), 0,
-                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
+        const bool edge = (M % 64) || (N % BN);
+        if (bf) { if (edge) XPS_LAUNCH_NTM(1, true, true); else XPS_LAUNCH_NTM(1, false, true); }
+        else { if (edge) XPS_LAUNCH_NTM(1, true, false); else XPS_LAUNCH_NTM(1, false, false); }
     } else {
-        if (M % 128 || N % BN)
-            hipLaunchKernelGGL((gemm_nt_multi_kernel<2, true>), dim3(cdiv(N, BN) * cdiv(M, 128) * nprob), dim3(256), 0,
-                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
-        else
-            hipLaunchKernelGGL((gemm_nt_multi_kernel<2>), dim3(cdiv(N, BN) * cdiv(M, 128) * nprob), dim3(256), 0,
-                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);
+        const bool edge = (M % 128) || (N % BN);
+        if (bf) { if (edge) XPS_LAUNCH_NTM(2, true, true); else XPS_LAUNCH_NTM(2, false, true); }
+        else { if (edge) XPS_LAUNCH_NTM(2, true, false); else XPS_LAUNCH_NTM(2, false, false); }
     }
+#undef XPS_LAUNCH_NTM
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
@@ -435,9 +450,14 @@ extern "C" int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra_, const floa
     rs.gs = 0; rs.ld = N; rs.rpg = 1 << 30;
     const long long slab_stride = (long long)M * N;
     dim3 grid(cdiv(N, BN) * cdiv(M, BM) * splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, (hipStream_t)stream,
-                       A, ra, B, rb, (const float*)nullptr, (const float*)nullptr, 0, slabs, rs, (const float*)nullptr,
-                       M, N, K, kchunk, slab_stride, 0, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
+    if (bf_mode())
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, true, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           A, ra, B, rb, (const float*)nullptr, (const float*)nullptr, 0, slabs, rs, (const float*)nullptr,
+                           M, N, K, kchunk, slab_stride, 0, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, (hipStream_t)stream,
+                           A, ra, B, rb, (const float*)nullptr, (const float*)nullptr, 0, slabs, rs, (const float*)nullptr,
+                           M, N, K, kchunk, slab_stride, 0, (int)map_vec_ok(A, ra), (int)map_vec_ok(B, rb));
     XPS_CHECK_LAUNCH();
     long long total = (long long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, RED_OUT)), dim3(256), 0, (hipStream_t)stream,
@@ -515,16 +535,29 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     }
     bool edge = false;
     for (int i = 0; i < n; ++i) edge = edge || (probs[i].M % BM) || (probs[i].N % BN);
-    if (edge)
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel<true>, dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    const bool bf = bf_mode();
+    if (bf && edge)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    else if (bf)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    else if (edge)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, false>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     else
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel<false>, dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, false>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     XPS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT)), dim3(256), 0, (hipStream_t)stream, g,
                        (const float*)workspace);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
+
+extern "C" int xps_set_gemm_precision(int mode) {
+    XPS_CHECK_ARG(mode == 0 || mode == 1, "mode: 0 = fp32 MFMA, 1 = bf16 split products");
+    gemm_mode().store(mode);
+    return XPS_OK;
+}
+
+extern "C" int xps_get_gemm_precision(void) { return gemm_mode().load(); }
 
 #ifdef XPS_GSTAMP
 extern "C" int xps_debug_read_gstamps(unsigned long long* host, int n) {

@@ -38,7 +38,9 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 }
 
 // Stages a (BKT x W) k-major tile of a matrix stored either [x][k] (KCONTIG) or [k][x]; W = 64 or 128.
-template <bool KCONTIG, int W>
+// BF: staging for the bf16 split-product pipeline (gemm_accumulate_bf): the [k][x] form hands every thread NV
+// CONSECUTIVE k rows of one 4-wide x group, so that the k-contiguous bf16 image can be written with packed stores.
+template <bool KCONTIG, int W, bool BF = false>
 struct TileLoader {
     // KCONTIG : 16-byte vectors along k; thread -> (x = tid / KL (+ XR per pass), k4 = (tid % KL) * 4)
     // !KCONTIG: 16-byte vectors along x; thread -> (k = tid / XL (+ KR per pass), x4 = (tid % XL) * 4)
@@ -48,6 +50,10 @@ struct TileLoader {
     static constexpr int XL = W / 4;                    // !KCONTIG: lanes per k row
     static constexpr int KR = 256 / XL;                 // !KCONTIG: k rows per pass
     static constexpr int NV = KCONTIG ? W / XR : BKT / KR;
+    static constexpr int KQ = BKT / NV;                 // !KCONTIG, BF: k groups (of NV consecutive rows) per tile
+    // !KCONTIG thread map: k row of register r, 4-wide x group of the thread
+    __device__ static inline int krow(int tid, int r) { return BF ? (tid % KQ) * NV + r : tid / XL + KR * r; }
+    __device__ static inline int xgrp(int tid) { return BF ? tid / KQ : tid % XL; }
     const float* base[NV];
     long long xoff[NV];
     long long kstride, kgs;       // !KCONTIG: row stride inside a group / group stride of the k rows
@@ -76,7 +82,7 @@ struct TileLoader {
             // edge tiles stay fast when whole 16-byte vectors are in or out (X % 4 == 0): out-of-range lanes read 0
             full = x0 + W <= X;
             fast = vec && (full || X % 4 == 0) && (plain || rm.rpg % BKT == 0);
-            const bool lane_in = x0 + (tid % XL) * 4 < X;
+            const bool lane_in = x0 + xgrp(tid) * 4 < X;
 #pragma unroll
             for (int r = 0; r < NV; ++r) ok[r] = lane_in;
             kstride = rm.ld;
@@ -84,7 +90,7 @@ struct TileLoader {
             krpg = plain ? 0 : rm.rpg;
 #pragma unroll
             for (int r = 0; r < NV; ++r)
-                base[r] = P + (long long)(tid / XL + KR * r) * rm.ld + (lane_in ? x0 + (tid % XL) * 4 : 0);
+                base[r] = P + (long long)krow(tid, r) * rm.ld + (lane_in ? x0 + xgrp(tid) * 4 : 0);
         }
     }
 
@@ -128,10 +134,10 @@ struct TileLoader {
                 v[r] = t;
             }
         } else {
-            const int x = x0 + (tid % XL) * 4;
+            const int x = x0 + xgrp(tid) * 4;
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
-                const int k = kt0 + tid / XL + KR * r;
+                const int k = kt0 + krow(tid, r);
                 f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < kend && x < X) {
                     const float* p = P + rm.off(k) + x;
@@ -290,6 +296,184 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float& csum, const 
     } else {
         gemm_pipeline<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, As, Bs);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 split-product pipeline.  Every fp32 operand element x is split while it is staged into LDS:
+//   hi = bf16(x),  lo = bf16(x - hi)      (x = hi + lo up to 2^-17 |x|)
+// and a product tile is accumulated in fp32 as  lo_a*hi_b + hi_a*lo_b + hi_a*hi_b  on v_mfma_f32_32x32x16_bf16:
+// three bf16 MFMAs (3 x 1/16 of the fp32-MFMA time) for a product exact to ~2^-16 relative (the dropped lo*lo term),
+// i.e. 256x tighter than a plain bf16 GEMM and within the 1e-4 parity bar of the model.  The C/D layout of the
+// 32x32 bf16 MFMA equals the fp32 form's, so gemm_store and every epilogue are shared with the fp32 pipeline.
+// LDS image per operand and buffer: hi[128][24] + lo[128][24] shorts: row = x (m or n), 16 k-contiguous bf16 + 16 B
+// pad -> 48-byte rows: the operand reads (ds_read_b128: lane -> row, k half) are bank-conflict free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int BFROW = 24;                                // shorts per LDS row (BKT = 16 used + 8 pad)
+static_assert(BKT == 16, "the bf16 pipeline maps one k-tile to one 32x32x16 MFMA step");
+struct BfTile {
+    __bf16 hi[128][BFROW];
+    __bf16 lo[128][BFROW];
+};
+struct BfStage {                                         // what a kernel declares in LDS: 2 buffers x (A, B)
+    BfTile a[2], b[2];
+};
+
+__device__ inline void bf_split(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+template <bool KCONTIG, int W>
+__device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], BfTile& S, int tid) {
+    using L = TileLoader<KCONTIG, W, true>;
+    if (KCONTIG) {
+        const int k4 = (tid % KL) * 4;
+#pragma unroll
+        for (int r = 0; r < L::NV; ++r) {
+            const int x = tid / KL + L::XR * r;
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+            *reinterpret_cast<bf16x4*>(&S.hi[x][k4]) = h;
+            *reinterpret_cast<bf16x4*>(&S.lo[x][k4]) = l;
+        }
+    } else {
+        // the thread holds k rows NV*kq .. NV*kq + NV-1 of x columns 4*xg .. 4*xg + 3: transpose in registers
+        constexpr int NV = L::NV;
+        const int k0 = (tid % L::KQ) * NV, x4 = (tid / L::KQ) * 4;
+        typedef __bf16 bfv __attribute__((ext_vector_type(NV > 1 ? NV : 2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (NV == 1) {
+                __bf16 a, b;
+                bf_split(v[0][j], a, b);
+                S.hi[x4 + j][k0] = a;
+                S.lo[x4 + j][k0] = b;
+            } else {
+                bfv h, l;
+#pragma unroll
+                for (int r = 0; r < NV; ++r) { __bf16 a, b; bf_split(v[r][j], a, b); h[r] = a; l[r] = b; }
+                *reinterpret_cast<bfv*>(&S.hi[x4 + j][k0]) = h;
+                *reinterpret_cast<bfv*>(&S.lo[x4 + j][k0]) = l;
+            }
+        }
+    }
+}
+
+// same contract as gemm_pipeline (MODE 0 guarded / 1 interior / 2 predicated edge)
+template <bool AK, bool BK, int MI, int MODE>
+__device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
+                                        const TileLoader<AK, 64 * MI, true>& la, const TileLoader<BK, 128, true>& lb,
+                                        const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
+                                        int M, int N, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage& S) {
+    constexpr int WM = 64 * MI;
+    using LA = TileLoader<AK, WM, true>;
+    using LB = TileLoader<BK, 128, true>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
+    const int li = lane & 31, lk = lane >> 5;
+    const int nkt = (kend - kbeg + BKT - 1) / BKT;
+
+    f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
+    if (nkt > 0) {
+        if (MODE) { la.template load_fast<MODE == 2>(ra0, kbeg); lb.template load_fast<MODE == 2>(rb0, kbeg); }
+        else { la.load(ra0, A, ra, m0, M, kbeg, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg, kend, tid, vecB); }
+        if (nkt > 1) {
+            if (MODE) { la.template load_fast<MODE == 2>(ra1, kbeg + BKT); lb.template load_fast<MODE == 2>(rb1, kbeg + BKT); }
+            else { la.load(ra1, A, ra, m0, M, kbeg + BKT, kend, tid, vecA); lb.load(rb1, B, rb, n0, N, kbeg + BKT, kend, tid, vecB); }
+        }
+        bf_store<AK, WM>(ra0, S.a[0], tid);
+        bf_store<BK, 128>(rb0, S.b[0], tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 2 < nkt) {
+            if (MODE) { la.template load_fast<MODE == 2>(ra0, kbeg + (kt + 2) * BKT); lb.template load_fast<MODE == 2>(rb0, kbeg + (kt + 2) * BKT); }
+            else { la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB); }
+        }
+        {
+            bf16x8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(&S.a[buf].hi[wm + i * 32 + li][lk * 8]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&S.a[buf].lo[wm + i * 32 + li][lk * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(&S.b[buf].hi[wn + j * 32 + li][lk * 8]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&S.b[buf].lo[wn + j * 32 + li][lk * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (want_csum) {
+            constexpr int G = 256 / WM, KG = BKT / G;          // k groups and k per group
+            const int cm = tid % WM, kh = (tid / WM) * KG;
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) csum += (float)S.a[buf].hi[cm][kh + kk] + (float)S.a[buf].lo[cm][kh + kk];
+        }
+        if (kt + 1 < nkt) {
+            bf_store<AK, WM>(ra1, S.a[buf ^ 1], tid);
+            bf_store<BK, 128>(rb1, S.b[buf ^ 1], tid);
+#pragma unroll
+            for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
+#pragma unroll
+            for (int r = 0; r < LB::NV; ++r) rb1[r] = rb0[r];
+        }
+        __syncthreads();
+    }
+}
+
+template <bool AK, bool BK, int MI, bool EDGE = false>
+__device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
+                                          const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
+                                          int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage& S) {
+    TileLoader<AK, 64 * MI, true> la;
+    TileLoader<BK, 128, true> lb;
+    la.init(A, ra, m0, M, K, threadIdx.x, vecA);
+    lb.init(B, rb, n0, N, K, threadIdx.x, vecB);
+    const int kfull = kbeg + ((kend - kbeg) / BKT) * BKT;
+    const bool both_fast = la.fast && lb.fast && kfull > kbeg;
+    const bool both_full = la.full && lb.full;
+    if (both_fast && both_full) {
+        gemm_pipeline_bf<AK, BK, MI, 1>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, S);
+        if (kfull < kend)
+            gemm_pipeline_bf<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, S);
+    } else if (EDGE && both_fast && !both_full) {
+        gemm_pipeline_bf<AK, BK, MI, 2>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, S);
+        if (kfull < kend)
+            gemm_pipeline_bf<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, S);
+    } else {
+        gemm_pipeline_bf<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, S);
+    }
+}
+
+// the staging memory of a tile kernel in either precision mode (BF = false: the fp32 k-major tiles)
+template <bool BF> struct TileMem;
+template <> struct TileMem<false> {
+    float As[2][BKT][LDT];
+    float Bs[2][BKT][LDT];
+};
+template <> struct TileMem<true> {
+    BfStage st;
+};
+template <bool AK, bool BK, int MI, bool EDGE, bool BF>
+__device__ inline void gemm_accumulate_any(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
+                                           const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
+                                           int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
+                                           TileMem<BF>& mem) {
+    if constexpr (BF) gemm_accumulate_bf<AK, BK, MI, EDGE>(acc, csum, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.st);
+    else gemm_accumulate<AK, BK, MI, EDGE>(acc, csum, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.As, mem.Bs);
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -12,7 +12,17 @@ def _xf():
     return XF
 
 
-def test_gemm_random_shapes_and_strides():
+@pytest.fixture(params=[0, 1], ids=['fp32', 'bf16x3'])
+def prec(request):
+    """Both product precisions of the tile kernels; yields the tolerance multiplier (see test_gpu_nn_kernels.TOL)."""
+    from cross_patient_speech_decoding_amd._lib import lib
+    old = lib().xps_get_gemm_precision()
+    assert lib().xps_set_gemm_precision(request.param) == 0
+    yield (1.0, 16.0)[request.param]
+    lib().xps_set_gemm_precision(old)
+
+
+def test_gemm_random_shapes_and_strides(prec):
     from cross_patient_speech_decoding_amd._lib import rowmap
     XF = _xf()
     rng = np.random.default_rng(2024)
@@ -34,7 +44,7 @@ def test_gemm_random_shapes_and_strides():
         XF.gemm_nt(A.cuda(), Bm.cuda(), out, M, N, K, bias=bias.cuda(), ra=rowmap(lda), rb=rowmap(ldb), rc=rowmap(ldc),
                    accumulate=acc)
         got = out.cpu()
-        assert ((got[:, :N].double() - ref).abs() <= 1e-6 * scale + 1e-30).all(), ('nt', M, N, K, lda, ldb, ldc, acc)
+        assert ((got[:, :N].double() - ref).abs() <= 1e-6 * prec * scale + 1e-30).all(), ('nt', M, N, K, lda, ldb, ldc, acc)
         assert torch.equal(got[:, N:], C0[:, N:]), ('nt padding touched', M, N, K)
         # NN with the same data: B given as (K x N)
         Bk = torch.zeros(K, ldc)
@@ -42,13 +52,13 @@ def test_gemm_random_shapes_and_strides():
         out2 = torch.full((M, ldc), 7.0).cuda()
         XF.gemm_nn(A.cuda(), Bk.cuda(), out2, M, N, K, ra=rowmap(lda), rb=rowmap(ldc), rc=rowmap(ldc))
         ref2 = A[:, :K].double() @ Bm[:, :K].double().T
-        assert ((out2.cpu()[:, :N].double() - ref2).abs() <= 1e-6 * scale + 1e-30).all(), ('nn', M, N, K, lda, ldc)
+        assert ((out2.cpu()[:, :N].double() - ref2).abs() <= 1e-6 * prec * scale + 1e-30).all(), ('nn', M, N, K, lda, ldc)
         # TN: out (M x N) = At^T B with At (K x M)
         At = torch.zeros(K, M + 3)
         At[:, :M] = A[:, :K].T
         out3 = torch.empty(M, N).cuda()
         XF.gemm_tn(At.cuda(), Bk.cuda(), out3, M, N, K, ra=rowmap(M + 3), rb=rowmap(ldc), rc=rowmap(N))
-        assert ((out3.cpu().double() - ref2).abs() <= 2e-6 * scale + 1e-30).all(), ('tn', M, N, K)
+        assert ((out3.cpu().double() - ref2).abs() <= 2e-6 * prec * scale + 1e-30).all(), ('tn', M, N, K)
 
 
 @pytest.mark.parametrize('seed', range(6))

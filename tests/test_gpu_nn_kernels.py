@@ -29,10 +29,34 @@ def dev(t):
 
 
 # ----------------------------------------------------------------------------- GEMM
+# The tile kernels run in one of two product precisions (include/xps.h xps_set_gemm_precision): fp32 MFMA (exact fp32
+# fma chains: a few ulp of the fp64 result) or bf16 split products (hi/lo split of both operands, three bf16 MFMAs:
+# per product |error| <= ~3 * 2^-18 |a||b| = 1.2e-5 |a||b|).  Every GEMM test runs in both and bounds the error by the
+# mode's constant times sum |a||b| — an indexing mistake would show up as an O(1) multiple of that sum.
+TOL = {0: 1.0, 1: 40.0}           # multiplier on the fp32 tolerances below (4e-7 * 40 = 1.6e-5)
+
+
+@pytest.fixture(params=[0, 1], ids=['fp32', 'bf16x3'])
+def prec(request):
+    from cross_patient_speech_decoding_amd._lib import lib
+    old = lib().xps_get_gemm_precision()
+    assert lib().xps_set_gemm_precision(request.param) == 0
+    yield TOL[request.param]
+    lib().xps_set_gemm_precision(old)
+
+
+def test_gemm_precision_switch_rejects_unknown_modes():
+    from cross_patient_speech_decoding_amd._lib import lib
+    old = lib().xps_get_gemm_precision()
+    assert old in (0, 1)
+    assert lib().xps_set_gemm_precision(7) != 0
+    assert lib().xps_get_gemm_precision() == old
+
+
 @pytest.mark.parametrize('M,N,K', [(1, 1, 1), (5, 9, 16), (37, 70, 100), (130, 129, 33), (300, 384, 256),
                                    (257, 100, 640), (64, 27, 6), (10, 384, 128), (16, 130, 77), (13, 70, 1031),
                                    (17, 64, 40)])
-def test_gemm_nt_nn_tn_exact_fp32(M, N, K):
+def test_gemm_nt_nn_tn_vs_fp64(M, N, K, prec):
     g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
     A = torch.randn(M, K, generator=g)
     Bm = torch.randn(N, K, generator=g)          # asymmetric random data (guide: never symmetric B)
@@ -42,26 +66,26 @@ def test_gemm_nt_nn_tn_exact_fp32(M, N, K):
     out = torch.empty(M, N, device='cuda')
     xf.gemm_nt(dev(A), dev(Bm), out, M, N, K, bias=dev(bias))
     scale = (A.abs().double() @ Bm.abs().double().T + bias.abs().double())
-    assert ((out.cpu().double() - ref).abs() <= 4e-7 * scale + 1e-30).all()
+    assert ((out.cpu().double() - ref).abs() <= 4e-7 * prec * scale + 1e-30).all()
     # accumulate
     xf.gemm_nt(dev(A), dev(Bm), out, M, N, K, accumulate=True)
     ref2 = ref + A.double() @ Bm.double().T
-    assert ((out.cpu().double() - ref2).abs() <= 1e-6 * scale + 1e-30).all()
+    assert ((out.cpu().double() - ref2).abs() <= 1e-6 * prec * scale + 1e-30).all()
     # NN: C = A (M x K) @ B (K x N)
     Bk = Bm.T.contiguous()
     out2 = torch.empty(M, N, device='cuda')
     xf.gemm_nn(dev(A), dev(Bk), out2, M, N, K)
     ref_nn = A.double() @ Bk.double()
-    assert ((out2.cpu().double() - ref_nn).abs() <= 4e-7 * scale + 1e-30).all()
+    assert ((out2.cpu().double() - ref_nn).abs() <= 4e-7 * prec * scale + 1e-30).all()
     # TN: C = At^T @ B, At (K x M), B (K x N)
     At = A.T.contiguous()
     out3 = torch.empty(M, N, device='cuda')
     xf.gemm_tn(dev(At), dev(Bk), out3, M, N, K)
-    assert ((out3.cpu().double() - ref_nn).abs() <= 4e-7 * scale + 1e-30).all()
+    assert ((out3.cpu().double() - ref_nn).abs() <= 4e-7 * prec * scale + 1e-30).all()
 
 
 @pytest.mark.parametrize('M,N,K1,K2', [(9, 100, 48, 48), (16, 65, 30, 7), (200, 100, 96, 96), (40, 33, 12, 50)])
-def test_gemm_nn2_two_operand_pairs(M, N, K1, K2):
+def test_gemm_nn2_two_operand_pairs(M, N, K1, K2, prec):
     """C = A1 B1 + A2 B2 in one launch (both directions of a bidirectional layer's input gradient)."""
     import ctypes as C
     from cross_patient_speech_decoding_amd._lib import call
@@ -82,24 +106,24 @@ def test_gemm_nn2_two_operand_pairs(M, N, K1, K2):
     torch.cuda.synchronize()
     ref = A1.double() @ B1.double() + A2.double() @ B2.double() + 3.0
     scale = A1.abs().double() @ B1.abs().double() + A2.abs().double() @ B2.abs().double() + 3.0
-    assert ((out.cpu().double() - ref).abs() <= 1e-6 * scale).all()
+    assert ((out.cpu().double() - ref).abs() <= 1e-6 * prec * scale).all()
 
 
-def test_gemm_tn_long_k_split():
+def test_gemm_tn_long_k_split(prec):
     g = torch.Generator().manual_seed(5)
     K, M, N = 20000, 48, 20
     At, Bk = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
     out = torch.full((M, N), 7.0, device='cuda')
     XF().gemm_tn(dev(At), dev(Bk), out, M, N, K, accumulate=True)
     ref = At.double().T @ Bk.double() + 7.0
-    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-4 * np.sqrt(K) / 100 + 1e-3)
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=0, atol=(2e-4 * np.sqrt(K) / 100 + 1e-3) * (1 if prec == 1.0 else 4))
     # determinism: bitwise identical on a second run
     out_b = torch.full((M, N), 7.0, device='cuda')
     XF().gemm_tn(dev(At), dev(Bk), out_b, M, N, K, accumulate=True)
     assert torch.equal(out, out_b)
 
 
-def test_gemm_rowmaps_conv_windows():
+def test_gemm_rowmaps_conv_windows(prec):
     """NT GEMM over strided convolution windows with a time-major result."""
     g = torch.Generator().manual_seed(9)
     B, T, Cin, F, k, s = 3, 23, 5, 7, 4, 3
@@ -112,7 +136,7 @@ def test_gemm_rowmaps_conv_windows():
     y = torch.empty(Tp, B, F, device='cuda')
     XF().gemm_nt(dev(x), dev(w2), y, Tp * B, F, k * Cin, bias=dev(bias),
                  ra=rowmap(s * Cin, rpg=Tp, gs=T * Cin), rc=rowmap(B * F, rpg=Tp, gs=F))
-    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5 if prec == 1.0 else 2e-4)
 
 
 def test_colsum_and_transpose():
