@@ -48,3 +48,6 @@ static inline RowMap to_rowmap(const xps_rowmap* r) {
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 __device__ inline float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// product precision of the matrix kernels (xps_set_gemm_precision): 0 = fp32 MFMA, 1 = bf16 split products
+int xps_internal_gemm_mode();

@@ -551,6 +551,8 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     return XPS_OK;
 }
 
+int xps_internal_gemm_mode() { return gemm_mode().load(std::memory_order_relaxed); }
+
 extern "C" int xps_set_gemm_precision(int mode) {
     XPS_CHECK_ARG(mode == 0 || mode == 1, "mode: 0 = fp32 MFMA, 1 = bf16 split products");
     gemm_mode().store(mode);

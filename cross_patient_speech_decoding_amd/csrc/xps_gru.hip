@@ -20,6 +20,9 @@
 #include <stdlib.h>
 #include "xps_common.h"
 #include "xps_gemm_tile.h"
+using xps_tile::bf16x4;
+using xps_tile::bf16x8;
+using xps_tile::bf_split;
 
 namespace {
 
@@ -384,11 +387,16 @@ __device__ unsigned long long g_stamp[4096 * 8];
 #define STAMP(var)
 #endif
 
-template <int H>
+// BF: the recurrent product h W_hh^T runs on the bf16 matrix pipe with split operands (W_hh split once into hi/lo
+// register fragments, h split when a step writes it to LDS; three v_mfma_f32_16x16x32_bf16 per product, see
+// xps_gemm_tile.h): the MFMA phase of a step shrinks from 192 x 32 to 72 x 16 cycles.
+template <int H, bool BF = false>
 __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p) {
     constexpr int NT = H / 16, TPW = NT / 4, NC = H / 16, LDH = H + 4;
+    constexpr int NCB = H / 32, LDB = H + 8;   // BF: 32-wide k chunks; bf16 row stride (conflict-free b128 reads)
     constexpr int NST = TPW * 5;               // 16-byte stores per lane and step: h, r, z, n, q per tile
     __shared__ __attribute__((aligned(16))) float hs[2][GBM][LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 hsb[BF ? 2 : 1][2][BF ? GBM : 1][BF ? LDB : 8];   // [buffer][hi, lo][trial][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const int dir = blockIdx.y, b0 = blockIdx.x * GBM;
@@ -406,7 +414,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
     STAMP(st_entry)
 #endif
 
-    float w[TPW][3][NC][4];                    // A operand: W[g*H + j0 + n][16c + 4kq + e]
+    float w[BF ? 1 : TPW][3][NC][4];           // A operand: W[g*H + j0 + n][16c + 4kq + e]
+    bf16x8 wh[BF ? TPW : 1][3][NCB], wl[BF ? TPW : 1][3][NCB];   // BF: W[g*H + j0 + n][32c + 8kq + j] split hi / lo
     float4 bias[TPW][3];                       // b_hh of the lane's 4 output units
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt)
@@ -414,10 +423,24 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
         for (int g = 0; g < 3; ++g) {
             const int j0 = (wave + 4 * tt) * 16;
             bias[tt][g] = *reinterpret_cast<const float4*>(bh + g * H + j0 + 4 * kq);
+            if constexpr (BF) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(W + (long long)(g * H + j0 + n) * H + 16 * c + 4 * kq);
-                w[tt][g][c][0] = v.x; w[tt][g][c][1] = v.y; w[tt][g][c][2] = v.z; w[tt][g][c][3] = v.w;
+                for (int c = 0; c < NCB; ++c) {
+                    const float* wp = W + (long long)(g * H + j0 + n) * H + 32 * c + 8 * kq;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(wp), v1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        __bf16 a, b;
+                        bf_split(v0[j], a, b); wh[tt][g][c][j] = a; wl[tt][g][c][j] = b;
+                        bf_split(v1[j], a, b); wh[tt][g][c][4 + j] = a; wl[tt][g][c][4 + j] = b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(W + (long long)(g * H + j0 + n) * H + 16 * c + 4 * kq);
+                    w[tt][g][c][0] = v.x; w[tt][g][c][1] = v.y; w[tt][g][c][2] = v.z; w[tt][g][c][3] = v.w;
+                }
             }
         }
 
@@ -436,6 +459,16 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
         }
     }
     __syncthreads();
+    if constexpr (BF) {
+        for (int i = tid; i < GBM * H; i += 256) {
+            const int r = i / H, k = i % H;
+            __bf16 a, b;
+            bf_split(hs[0][r][k], a, b);
+            hsb[0][0][r][k] = a; hsb[0][1][r][k] = b;
+            hsb[1][0][r][k] = (__bf16)0.f; hsb[1][1][r][k] = (__bf16)0.f;
+        }
+        __syncthreads();
+    }
 
     // Results of step s are NOT stored at the end of step s: a CU retires stores at ~16 B/clk, so 40 KB
     // per step would stall every wave ~2400 cycles at issue.  They are kept in registers (pend) and
@@ -481,6 +514,32 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool flush = (s > 0) && live;
+        if constexpr (BF) {
+            bf16x8 hbh[2], hbl[2];
+            hbh[0] = *reinterpret_cast<const bf16x8*>(&hsb[cur][0][n][8 * kq]);
+            hbl[0] = *reinterpret_cast<const bf16x8*>(&hsb[cur][1][n][8 * kq]);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                if (c + 1 < NCB) {
+                    hbh[(c + 1) & 1] = *reinterpret_cast<const bf16x8*>(&hsb[cur][0][n][32 * (c + 1) + 8 * kq]);
+                    hbl[(c + 1) & 1] = *reinterpret_cast<const bf16x8*>(&hsb[cur][1][n][32 * (c + 1) + 8 * kq]);
+                }
+                const bf16x8 bh8 = hbh[c & 1], bl8 = hbl[c & 1];
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[tt][g][c], bh8, acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][g][c], bl8, acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][g][c], bh8, acc[tt][g], 0, 0, 0);
+                    }
+                if (flush) {
+#pragma unroll
+                    for (int k = c; k < NST; k += NCB) issue_store(k);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         float4 hb[2];
         hb[0] = *reinterpret_cast<const float4*>(&hs[cur][n][4 * kq]);
 #pragma unroll
@@ -499,6 +558,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
                 for (int k = c; k < NST; k += NC) issue_store(k);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         STAMP(st1)
         if (s + 1 < T) {
@@ -531,6 +591,13 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
             pend[3 * TPW + tt] = make_float4(n_[0], n_[1], n_[2], n_[3]);
             pend[4 * TPW + tt] = make_float4(q_[0], q_[1], q_[2], q_[3]);
             *reinterpret_cast<float4*>(&hs[cur ^ 1][n][j]) = pend[tt];
+            if constexpr (BF) {
+                bf16x4 sh, sl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __bf16 a, b; bf_split(o[i], a, b); sh[i] = a; sl[i] = b; }
+                *reinterpret_cast<bf16x4*>(&hsb[cur ^ 1][0][n][j]) = sh;
+                *reinterpret_cast<bf16x4*>(&hsb[cur ^ 1][1][n][j]) = sl;
+            }
         }
         pend_y = p.y_ext + ((long long)(t + 1) * B + bc) * ldy + dir * H;
         pend_sv = do_save ? p.saved + (((long long)dir * T + t) * B + bc) * 4 * H : nullptr;
@@ -561,11 +628,13 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
 #endif
 }
 
-template <int H>
+template <int H, bool BF = false>
 __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p) {
     constexpr int NT = H / 16, TPW = NT / 4, NC = 3 * H / 16, LDG = 3 * H + 4, LDC = H + 4;
+    constexpr int NCB = 3 * H / 32, LDGB = 3 * H + 8;     // BF: 32-wide k chunks; bf16 row stride of the gate gradients
     constexpr int H4 = H / 4, GPT = GBM * H4 / 256;       // float4 groups of the 16 x H tile per thread
-    __shared__ __attribute__((aligned(16))) float G[GBM][LDG];
+    __shared__ __attribute__((aligned(16))) float G[BF ? 1 : GBM][BF ? 4 : LDG];
+    __shared__ __attribute__((aligned(16))) __bf16 Gb[2][BF ? GBM : 1][BF ? LDGB : 8];      // BF: [hi, lo][trial][k]
     __shared__ __attribute__((aligned(16))) float Cy[GBM][LDC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
@@ -574,17 +643,36 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
     const int ldy = p.ndir * H;
     const float* __restrict__ WT = p.w_hh_t[dir];   // (H x 3H)
 
-    float w[TPW][NC][4];                             // A operand: WT[j0 + n][16c + 4kq + e]
+    float w[BF ? 1 : TPW][NC][4];                    // A operand: WT[j0 + n][16c + 4kq + e]
+    bf16x8 wh[BF ? TPW : 1][NCB], wl[BF ? TPW : 1][NCB];   // BF: WT[j0 + n][32c + 8kq + j] split hi / lo
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         const int j = (wave + 4 * tt) * 16 + n;
+        if constexpr (BF) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(WT + (long long)j * 3 * H + 16 * c + 4 * kq);
-            w[tt][c][0] = v.x; w[tt][c][1] = v.y; w[tt][c][2] = v.z; w[tt][c][3] = v.w;
+            for (int c = 0; c < NCB; ++c) {
+                const float* wp = WT + (long long)j * 3 * H + 32 * c + 8 * kq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(wp), v1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, b;
+                    bf_split(v0[e], a, b); wh[tt][c][e] = a; wl[tt][c][e] = b;
+                    bf_split(v1[e], a, b); wh[tt][c][4 + e] = a; wl[tt][c][4 + e] = b;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(WT + (long long)j * 3 * H + 16 * c + 4 * kq);
+                w[tt][c][0] = v.x; w[tt][c][1] = v.y; w[tt][c][2] = v.z; w[tt][c][3] = v.w;
+            }
         }
     }
-    for (int i = tid; i < GBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
+    if constexpr (BF) {
+        for (int i = tid; i < 2 * GBM * LDGB; i += 256) (&Gb[0][0][0])[i] = (__bf16)0.f;
+    } else {
+        for (int i = tid; i < GBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
+    }
     for (int i = tid; i < GBM * LDC; i += 256) (&Cy[0][0])[i] = 0.f;
     __syncthreads();
     if (p.dhn) {
@@ -661,9 +749,23 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
                 dan4 = make_float4(o_dan[0], o_dan[1], o_dan[2], o_dan[3]);
             }
             pend[e * 4 + 0] = dar; pend[e * 4 + 1] = daz; pend[e * 4 + 2] = dan4; pend[e * 4 + 3] = danr;
-            *reinterpret_cast<float4*>(&G[r][j]) = dar;
-            *reinterpret_cast<float4*>(&G[r][H + j]) = daz;
-            *reinterpret_cast<float4*>(&G[r][2 * H + j]) = danr;
+            if constexpr (BF) {
+                auto put = [&](const float4& v, int col) {
+                    bf16x4 sh, sl;
+                    __bf16 a, b;
+                    bf_split(v.x, a, b); sh[0] = a; sl[0] = b;
+                    bf_split(v.y, a, b); sh[1] = a; sl[1] = b;
+                    bf_split(v.z, a, b); sh[2] = a; sl[2] = b;
+                    bf_split(v.w, a, b); sh[3] = a; sl[3] = b;
+                    *reinterpret_cast<bf16x4*>(&Gb[0][r][col]) = sh;
+                    *reinterpret_cast<bf16x4*>(&Gb[1][r][col]) = sl;
+                };
+                put(dar, j); put(daz, H + j); put(danr, 2 * H + j);
+            } else {
+                *reinterpret_cast<float4*>(&G[r][j]) = dar;
+                *reinterpret_cast<float4*>(&G[r][H + j]) = daz;
+                *reinterpret_cast<float4*>(&G[r][2 * H + j]) = danr;
+            }
             *reinterpret_cast<float4*>(&Cy[r][j]) = keep;
         }
         auto issue_store = [&](int k) {        // k compile-time at every call site
@@ -684,6 +786,29 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
             const float4 c4 = *reinterpret_cast<const float4*>(&Cy[n][(wave + 4 * tt) * 16 + 4 * kq]);
             acc[tt] = (f32x4){c4.x, c4.y, c4.z, c4.w};
         }
+        if constexpr (BF) {
+            bf16x8 gbh[2], gbl[2];
+            gbh[0] = *reinterpret_cast<const bf16x8*>(&Gb[0][n][8 * kq]);
+            gbl[0] = *reinterpret_cast<const bf16x8*>(&Gb[1][n][8 * kq]);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                if (c + 1 < NCB) {
+                    gbh[(c + 1) & 1] = *reinterpret_cast<const bf16x8*>(&Gb[0][n][32 * (c + 1) + 8 * kq]);
+                    gbl[(c + 1) & 1] = *reinterpret_cast<const bf16x8*>(&Gb[1][n][32 * (c + 1) + 8 * kq]);
+                }
+                const bf16x8 bh8 = gbh[c & 1], bl8 = gbl[c & 1];
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) {
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[tt][c], bh8, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][c], bl8, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][c], bh8, acc[tt], 0, 0, 0);
+                }
+                if (c < NST) issue_store(c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = NCB; k < NST; ++k) issue_store(k);
+        } else {
         float4 gb[2];
         gb[0] = *reinterpret_cast<const float4*>(&G[n][4 * kq]);
 #pragma unroll
@@ -700,6 +825,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
         }
 #pragma unroll
         for (int k = NC / 2 + (NC % 2); k < NST; ++k) issue_store(k);
+        }
         const bool live = b0 + n < B;
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
@@ -1007,8 +1133,11 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     }
     dim3 grid(cdiv(B, GBM), ndir);
     if (vec && (H == 128 || H == 64)) {
-        if (H == 128) hipLaunchKernelGGL(gru_fwd_resident_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(gru_fwd_resident_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        const bool bf = xps_internal_gemm_mode() == 1;
+        if (H == 128 && bf) hipLaunchKernelGGL((gru_fwd_resident_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (H == 128) hipLaunchKernelGGL((gru_fwd_resident_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (bf) hipLaunchKernelGGL((gru_fwd_resident_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gru_fwd_resident_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
         XPS_CHECK_LAUNCH();
         return XPS_OK;
     }
@@ -1088,8 +1217,11 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
     }
     dim3 grid(cdiv(B, GBM), ndir);
     if (vec && (H == 128 || H == 64)) {
-        if (H == 128) hipLaunchKernelGGL(gru_bwd_resident_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(gru_bwd_resident_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        const bool bf = xps_internal_gemm_mode() == 1;
+        if (H == 128 && bf) hipLaunchKernelGGL((gru_bwd_resident_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (H == 128) hipLaunchKernelGGL((gru_bwd_resident_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (bf) hipLaunchKernelGGL((gru_bwd_resident_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gru_bwd_resident_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
         XPS_CHECK_LAUNCH();
         return XPS_OK;
     }
