@@ -21,7 +21,7 @@
 #include "xps_gemm_tile.h"
 using namespace xps_tile;
 #ifndef XPS_GEMM_DEFAULT_MODE
-#define XPS_GEMM_DEFAULT_MODE 0
+#define XPS_GEMM_DEFAULT_MODE 1
 #endif
 namespace {
 

@@ -31,6 +31,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+GEMM_PRECISIONS = {'fp32': 0, 'bf16x3': 1}
+
+
+def set_gemm_precision(name):
+    """Product precision of the matrix kernels (GEMMs and the fused GRU recurrence): 'bf16x3' (default: operands split
+    hi + lo in bf16, three bf16 MFMAs per product, fp32 accumulate: ~2^-16 relative product error, logits within 2e-6
+    of the reference goldens) or 'fp32' (fp32 MFMA, exact fp32 fma chains).  Process-wide; also XPS_GEMM_PRECISION."""
+    if name not in GEMM_PRECISIONS:
+        raise ValueError(f"gemm precision must be one of {sorted(GEMM_PRECISIONS)}")
+    call('xps_set_gemm_precision', GEMM_PRECISIONS[name])
+
+
+def get_gemm_precision():
+    mode = lib().xps_get_gemm_precision()
+    return {v: k for k, v in GEMM_PRECISIONS.items()}[mode]
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:

@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=['fp32', 'bf16x3'])
+def gemm_precision(request):
+    """Runs a GPU test in both product precisions of the matrix kernels (include/xps.h xps_set_gemm_precision);
+    yields the mode name and restores the previous mode."""
+    from cross_patient_speech_decoding_amd._lib import lib
+    old = lib().xps_get_gemm_precision()
+    assert lib().xps_set_gemm_precision({'fp32': 0, 'bf16x3': 1}[request.param]) == 0
+    yield request.param
+    lib().xps_set_gemm_precision(old)

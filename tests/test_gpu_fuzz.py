@@ -62,7 +62,7 @@ def test_gemm_random_shapes_and_strides(prec):
 
 
 @pytest.mark.parametrize('seed', range(6))
-def test_gru_layer_random_shapes(seed):
+def test_gru_layer_random_shapes(seed, gemm_precision):
     """GRULayerFn forward + backward vs torch.nn.GRU on the CPU for random (T, B, In, H, ndir)."""
     XF = _xf()
     rng = np.random.default_rng(100 + seed)

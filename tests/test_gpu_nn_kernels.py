@@ -167,7 +167,7 @@ def _weights(gru, ndir):
 
 @pytest.mark.parametrize('T,B,In,H,ndir', [(1, 5, 6, 16, 1), (7, 5, 6, 16, 2), (4, 33, 9, 20, 2), (20, 40, 100, 128, 2),
                                            (3, 17, 8, 6, 2), (5, 16, 12, 500, 1), (6, 21, 10, 64, 2), (9, 130, 24, 128, 1), (4, 150, 40, 256, 2), (3, 70, 24, 200, 2), (2, 33, 16, 132, 1)])
-def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir):
+def test_gru_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir, gemm_precision):
     torch.set_num_threads(4)
     gru = _cpu_gru(In, H, ndir, seed=T * 100 + H)
     g = torch.Generator().manual_seed(1)
@@ -259,7 +259,7 @@ def test_dropout_kernel_statistics_and_backward():
     assert xf.dropout(x, 0.3, False) is x
 
 
-def test_gru_recurrence_with_h0_and_dh0():
+def test_gru_recurrence_with_h0_and_dh0(gemm_precision):
     torch.set_num_threads(4)
     T, B, H = 1, 9, 24
     gru = _cpu_gru(H, H, 1, seed=3)

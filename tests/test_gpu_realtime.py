@@ -22,7 +22,7 @@ def build(g):
     return m.cuda().eval(), (C, win, stride, H, L, ncls)
 
 
-def test_forward_matches_reference_golden(golden_dir):
+def test_forward_matches_reference_golden(golden_dir, gemm_precision):
     from cross_patient_speech_decoding_amd.realtime_sim import greedy_decode_batch
     g = np.load(os.path.join(golden_dir, 'realtime_small.npz'))
     m, _ = build(g)
@@ -118,7 +118,7 @@ def test_ctc_kernel_vs_torch_cpu(T, B, C, L):
         XF.ctc_loss(logits.cuda(), targets.cuda(), il + T, tl)
 
 
-def test_ctc_training_step_matches_reference_golden(golden_dir):
+def test_ctc_training_step_matches_reference_golden(golden_dir, gemm_precision):
     """Loss, PER and every parameter gradient of the reference's training / validation / test steps."""
     g = np.load(os.path.join(golden_dir, 'realtime_train_small.npz'))
     m, (C, win, stride, H, L, ncls) = build(g)

@@ -29,7 +29,7 @@ def build_hip(cfg, seed, dropout=0.0):
 
 
 @pytest.mark.parametrize('name', ['tiny', 'tiny_relu_dec2', 'cfg2'])
-def test_eval_logits_and_argmax_match_reference_golden(golden_dir, name):
+def test_eval_logits_and_argmax_match_reference_golden(golden_dir, name, gemm_precision):
     g = np.load(os.path.join(golden_dir, f'seq2seq_{name}.npz'))
     cfg = ast.literal_eval(str(g['cfg']))
     m = build_hip(cfg, int(g['seed'])).eval()
@@ -45,7 +45,7 @@ def test_eval_logits_and_argmax_match_reference_golden(golden_dir, name):
 
 @pytest.mark.parametrize('name', ['tiny', 'tiny_relu_dec2', 'cfg2'])
 @pytest.mark.parametrize('tag,coin', [('tf1', True), ('tf0', False)])
-def test_train_step_matches_reference_golden(golden_dir, name, tag, coin):
+def test_train_step_matches_reference_golden(golden_dir, name, tag, coin, gemm_precision):
     from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
     g = np.load(os.path.join(golden_dir, f'seq2seq_{name}.npz'))
     cfg = ast.literal_eval(str(g['cfg']))
@@ -70,7 +70,14 @@ def test_train_step_matches_reference_golden(golden_dir, name, tag, coin):
         for k, v in m.state_dict().items():
             if k == NOISE_KEY:
                 continue
-            np.testing.assert_allclose(v.cpu().numpy(), g[f'{tag}_after/{k}'], rtol=1e-4, atol=2e-5, err_msg=k)
+            got, ref = v.cpu().numpy(), g[f'{tag}_after/{k}']
+            if gemm_precision == 'bf16x3' and f'{tag}_grad/{k}' in g:
+                # Adam's first step moves a weight by lr * g / (|g| + eps) ~ lr * sign(g): elements whose gradient is at
+                # the noise floor of the split products (1e-5 of the largest) can move the other way; compare the rest
+                gr = np.abs(g[f'{tag}_grad/{k}'])
+                keep = gr > 1e-3 * gr.max()
+                got, ref = got[keep], ref[keep]
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=k)
     else:
         for k, p in params.items():
             if k == NOISE_KEY:
@@ -82,7 +89,7 @@ def test_train_step_matches_reference_golden(golden_dir, name, tag, coin):
         np.testing.assert_allclose(after[keep], g[f'{tag}_after_sum'][keep], rtol=1e-4, atol=2e-3)
 
 
-def test_seeded_larger_batch_vs_oracle():
+def test_seeded_larger_batch_vs_oracle(gemm_precision):
     """cfg-2 architecture, B = 96 (partial 16-row tiles), random seeded weights: HIP vs the CPU oracle."""
     from oracle.seq2seq_oracle import Seq2SeqOracle
     torch.set_num_threads(8)
