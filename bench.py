@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 CFG = dict(in_channels=64, n_filters=100, hidden_size=128, num_classes=9, n_enc_layers=2, n_dec_layers=1,
            kernel_size=10, stride=10, T=200, trials_per_gpu=2048)
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x4, 64 FLOP/clk/SIMD
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def train_flops_per_trial(c):
@@ -164,6 +166,7 @@ def time_dominant_kernel(model, c, captured=None):
         dur = _event_time(lambda: XF.gemm_tn_grouped(probs_real, dev))
         operands = 'operands captured from a training step'
     ach = flops / dur / 1e12
+    precision = XF.get_gemm_precision()
     # second: the fused GRU recurrence of one encoder layer (both directions, one launch)
     rnn = model.encoder.rnn
     w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
@@ -171,23 +174,46 @@ def time_dominant_kernel(model, c, captured=None):
     gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
     dur_gru = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True))
     fl_gru = 2 * Tp * B * 2 * 3 * H * H
+    by_gru = 4 * 2 * Tp * B * (3 * H + H + 4 * H)          # gi in, y + saved gates (r, z, n, q) out
     # HBM traffic of this launch from the PMC counters (collected offline with rocprofv3 --pmc, separate passes,
     # gfx950 FETCH_SIZE correction applied): profiles/round1/pmc_traffic.json
     traffic = None
     try:
         with open(os.path.join(ROOT, 'profiles', 'round1', 'pmc_traffic.json')) as f:
-            traffic = json.load(f)['gemm_tn_grouped_kernel']['hbm_bytes_per_launch']
+            key = 'gemm_tn_grouped_kernel' + ('' if precision == 'fp32' else '_' + precision)
+            traffic = json.load(f)[key]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         pass
-    return {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel (fp32 MFMA 128x128x16 tile; encoder layer-1 weight '
-                                       'gradients, 6 problems in one launch, incl. its reduce pass)',
-            'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-            'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops, 'operands': operands,
-            'random_operands': {'achieved': round(flops / dur_rand / 1e12, 3), 'launch_us': round(dur_rand * 1e6, 1)},
-            'also': {'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions)',
-                     'achieved': round(fl_gru / dur_gru / 1e12, 3), 'frac': round(fl_gru / dur_gru / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-                     'launch_us': round(dur_gru * 1e6, 1), 'flops_per_launch': fl_gru}}
+    # algorithmic HBM bytes of the launch: every operand row read once (dgi, dghn, x, h_prev of both directions),
+    # gradients written once
+    bytes_alg = 4 * (K * (2 * 3 * H + 2 * H + In + 2 * H) + 2 * (3 * H * H + 3 * H * In + 6 * H))
+    common = {'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops, 'bytes_per_launch': bytes_alg, 'operands': operands,
+              'traffic': traffic, 'precision': precision,
+              'random_operands': {'launch_us': round(dur_rand * 1e6, 1)}}
+    if precision == 'fp32':
+        out = {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel (fp32 MFMA 128x128x16 tile; encoder layer-1 weight '
+                                          'gradients, 6 problems in one launch, incl. its reduce pass)',
+               'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+               'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4)}
+        out.update(common)
+        out['also'] = {'kernel': 'gru_fwd_resident_kernel<128> (encoder layer, both directions)',
+                       'achieved': round(fl_gru / dur_gru / 1e12, 3), 'frac': round(fl_gru / dur_gru / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                       'launch_us': round(dur_gru * 1e6, 1), 'flops_per_launch': fl_gru}
+        return out
+    # bf16 split products: three bf16 MFMAs per algorithmic multiply-add.  The matrix pipe is no longer what binds
+    # (issued MFMA work = 3 * flops is reported beside it); the launch is priced against HBM: algorithmic bytes / time.
+    gbs = bytes_alg / dur / 1e9
+    out = {'bound': 'hbm', 'kernel': 'gemm_tn_grouped_kernel<bf16x3> (128x128x16 tile, operands split hi/lo while staged, 3 bf16 '
+                                     'MFMAs per product; encoder layer-1 weight gradients, 6 problems in one launch, incl. its reduce pass)',
+           'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+    out.update(common)
+    out['mfma_side'] = {'algorithmic_tflops': round(ach, 2), 'issued_bf16_tflops': round(3 * ach, 2), 'peak': BF16_MFMA_PEAK_TFLOPS,
+                        'issued_frac': round(3 * ach / BF16_MFMA_PEAK_TFLOPS, 4)}
+    gru_gbs = by_gru / dur_gru / 1e9
+    out['also'] = {'kernel': 'gru_fwd_resident_kernel<128, bf16x3> (encoder layer, both directions)', 'bound': 'hbm',
+                   'achieved': round(gru_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gru_gbs / HBM_PEAK_GBS, 4),
+                   'launch_us': round(dur_gru * 1e6, 1), 'bytes_per_launch': by_gru, 'flops_per_launch': fl_gru}
+    return out
 
 
 def main():
@@ -196,6 +222,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default=None,
+                    help='product precision of the matrix kernels (default: the library default, bf16x3)')
     ap.add_argument('--hidden', type=int, default=None, help='(exploration only) override the hidden size, e.g. 512 = cfg 4')
     ap.add_argument('--channels', type=int, default=None, help='(exploration only) override the input channels')
     args = ap.parse_args()
@@ -219,6 +247,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    if args.precision:
+        XF.set_gemm_precision(args.precision)
+    precision = XF.get_gemm_precision()
     c = dict(CFG)
     if args.hidden:
         c['hidden_size'] = args.hidden
@@ -284,7 +316,11 @@ def main():
             'metric': 'ECoG trials/sec seq2seq-RNN training', 'value': round(value, 1), 'unit': 'trials/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(el / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            # bf16x3: every fp32 operand split hi + lo in bf16, 3 bf16 MFMAs per product, fp32 accumulation and fp32 everywhere
+            # else (results within 2e-6 of the fp32 reference goldens); fp32: fp32 MFMA
+            'dtype': 'bf16x3-split MFMA products, f32 accumulate' if precision == 'bf16x3' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': 'configs[1]: single-patient seq2seq GRU, H=128, T=200 (T\'=20), C=64, F=100, '
                                    'enc 2x bi-GRU, dec 1x GRU, full-batch step of 2048 trials per GPU, '
                                    'dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW',

@@ -497,7 +497,7 @@ __device__ inline void gemm_store(const f32x16 (&acc)[MI][2], float* __restrict_
                     float v = acc[i][j][r];
                     if (bias) v += bias[col];
                     if (accumulate) v += crow[col];
-                    crow[col] = v;
+                    __builtin_nontemporal_store(v, &crow[col]);        // streamed once: -1 % on the step vs a plain store
                 }
             }
         }
