@@ -1,5 +1,7 @@
-// Dense fp32 GEMMs on the f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fma
-// chains, 64 FLOP/clk/SIMD = the fp32 matrix peak of gfx950 (157 TFLOP/s).
+// Dense fp32 GEMMs in two product precisions (xps_set_gemm_precision): the f32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chains, 64 FLOP/clk/SIMD = 157 TFLOP/s) described
+// below, or the bf16 split-product pipeline of xps_gemm_tile.h (template flag BF: operands split
+// hi/lo on the way into LDS, three v_mfma_f32_32x32x16_bf16 per product; the default).
 //
 // One LDS-tiled kernel, 128 x 128 x 16 block tile, 4 waves each owning a 64 x 64
 // sub-tile (2 x 2 MFMA 32x32 tiles).  Both operands are staged k-major in LDS

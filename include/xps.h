@@ -52,8 +52,8 @@ int xps_abi_version(void);
 /* a HIP stream at the lowest priority of the device (for work that must yield to the caller's main stream) */
 int xps_stream_create_low_priority(void** stream);
 int xps_stream_destroy(void* stream);
-/* Product precision of the tiled GEMM entry points below (xps_gemm_*): 0 = fp32 MFMA, exact fp32 fma chains;
- * 1 = bf16 split products: every fp32 operand is split hi + lo in bf16 while it is staged and a product is
+/* Product precision of the tiled GEMM entry points below (xps_gemm_*) and of the fused GRU recurrence (xps_gru_seq_*,
+ * H <= 128): 0 = fp32 MFMA, exact fp32 fma chains; 1 = bf16 split products (the default): every fp32 operand is split hi + lo in bf16 while it is staged and a product is
  * accumulated in fp32 as lo*hi + hi*lo + hi*hi on the bf16 matrix pipe (relative product error ~2^-16; results
  * stay inside the 1e-4 parity bar; BASELINE.json names bf16 for this path).  Process-wide, initial value from
  * XPS_GEMM_PRECISION=fp32|bf16x3; returns XPS_E_INVALID for other modes. */
@@ -61,7 +61,8 @@ int xps_set_gemm_precision(int mode);
 int xps_get_gemm_precision(void);
 
 /* ------------------------------------------------------------------------- */
-/* Dense fp32 contractions on the f32-input MFMA (exact fp32 fma chains).      */
+/* Dense fp32 contractions: bf16 split products (default) or the f32-input     */
+/* MFMA with exact fp32 fma chains (xps_set_gemm_precision above).              */
 /* Replaces the GEMMs inside torch.nn.Conv1d / nn.GRU / nn.Linear and their     */
 /* autograd (nn_models/models.py:616,661,739,746).                               */
 /* ------------------------------------------------------------------------- */
