@@ -268,11 +268,13 @@ def main():
     torch.manual_seed(99)                        # the same teacher-forcing coins on every rank
     model.train()
 
+    one = torch.ones((), device=dev)
+
     def step():
         opt.zero_grad()
         logits = model(X, y, teacher_forcing_ratio=0.5)
         loss = model.criterion(logits.view(-1, c['num_classes']), y.view(-1))
-        loss.backward()
+        loss.backward(one)                       # a resident 1.0 as the root gradient (autograd would launch a fill)
         opt.step()
         return loss
 

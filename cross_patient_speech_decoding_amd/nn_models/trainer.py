@@ -307,7 +307,10 @@ class Trainer:
                 loss = model.training_step(batch, bi)
                 if world > 1:                       # global mean over unequal shards
                     loss = loss * (x.shape[0] * world / n_global)
-                loss.backward()
+                one = self.__dict__.get('_one')
+                if one is None or one.device != loss.device or one.dtype != loss.dtype:
+                    one = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+                loss.backward(one)                  # resident root gradient: no fill launch per step
                 self.optimizer.step()
                 n = x.shape[0]
                 for k, v in model._xps_logged.items():
