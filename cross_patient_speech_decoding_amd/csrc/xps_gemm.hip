@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
-    gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem);
-    if (A2) gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, mem);
+    f32x4 nocs4 = {0.f, 0.f, 0.f, 0.f};
+    gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, nocs4, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem);
+    if (A2) gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, nocs4, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, mem);
     gemm_store<MI>(acc, C + (long long)z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     f32x16 acc[MI][2];
     zero_acc<MI>(acc);
     float nocs = 0.f;
-    gemm_accumulate_any<true, true, MI, EDGE, BF>(acc, nocs, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, mem);
+    f32x4 nocs4 = {0.f, 0.f, 0.f, 0.f};
+    gemm_accumulate_any<true, true, MI, EDGE, BF>(acc, nocs, nocs4, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, mem);
     gemm_store<MI>(acc, pm.C[z], rc, pm.bias[z], M, N, m0, n0, 0);
 }
 
@@ -197,10 +199,26 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     f32x16 acc[2][2];
     zero_acc<2>(acc);
     float csum = 0.f;
-    gemm_accumulate_any<false, false, 2, EDGE, BF>(acc, csum, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
+    f32x4 csum4 = {0.f, 0.f, 0.f, 0.f};
+    gemm_accumulate_any<false, false, 2, EDGE, BF>(acc, csum, csum4, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
                                                    kbeg, kend, P.vecA, P.vecB, mem);
     gemm_store<2>(acc, slab, rs, nullptr, P.M, P.N, tm * BM, tn * BN, 0);
-    if (cs) {                                   // fold the two k-groups of the column sums through LDS
+    if (BF && cs) {
+        // bf16 pipeline: thread (kq = tid % 8, x group = tid / 8) holds the sums of columns 4 xg .. 4 xg + 3 over its k rows;
+        // the 8 kq lanes are adjacent: fold them with a fixed xor tree, lane kq = 0 writes
+        using LA = TileLoader<false, 128, true>;
+        static_assert(LA::KQ == 8, "column-sum fold assumes 8 k groups per tile");
+#pragma unroll
+        for (int off = 1; off < LA::KQ; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum4[j] += __shfl_xor(csum4[j], off);
+        const int tid = threadIdx.x, x4 = (tid / LA::KQ) * 4;
+        if (tid % LA::KQ == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (tm * BM + x4 + j < P.M) cs[x4 + j] = csum4[j];
+        }
+    } else if (cs) {                            // fold the two k-groups of the column sums through LDS
         const int tid = threadIdx.x;
         float* red = reinterpret_cast<float*>(&mem);
         __syncthreads();

@@ -363,9 +363,20 @@ __device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::N
     }
 }
 
-// same contract as gemm_pipeline (MODE 0 guarded / 1 interior / 2 predicated edge)
+// Column sums of the A operand (bias gradient of the TN form) from the staging REGISTERS, before the split: every k-tile
+// passes through them exactly once.  [k][x] form only: the thread's running sums are those of its 4 x columns over its
+// NV k rows; the KQ threads (adjacent lanes) that share the x group are folded by the kernel with lane shuffles.
+template <bool KCONTIG, int W>
+__device__ inline void bf_colsum(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], f32x4& cs) {
+    if constexpr (!KCONTIG) {           // (never requested for [x][k] operands)
+#pragma unroll
+        for (int r = 0; r < TileLoader<KCONTIG, W, true>::NV; ++r) cs += v[r];
+    }
+}
+
+// same contract as gemm_pipeline (MODE 0 guarded / 1 interior / 2 predicated edge); csum: see bf_colsum
 template <bool AK, bool BK, int MI, int MODE>
-__device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
+__device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const bool want_csum,
                                         const TileLoader<AK, 64 * MI, true>& la, const TileLoader<BK, 128, true>& lb,
                                         const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                         int M, int N, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage& S) {
@@ -387,6 +398,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], float& csum, const
         }
         bf_store<AK, WM>(ra0, S.a[0], tid);
         bf_store<BK, 128>(rb0, S.b[0], tid);
+        if (want_csum) bf_colsum<AK, WM>(ra0, csum);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -416,15 +428,10 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], float& csum, const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (want_csum) {
-            constexpr int G = 256 / WM, KG = BKT / G;          // k groups and k per group
-            const int cm = tid % WM, kh = (tid / WM) * KG;
-#pragma unroll
-            for (int kk = 0; kk < KG; ++kk) csum += (float)S.a[buf].hi[cm][kh + kk] + (float)S.a[buf].lo[cm][kh + kk];
-        }
         if (kt + 1 < nkt) {
             bf_store<AK, WM>(ra1, S.a[buf ^ 1], tid);
             bf_store<BK, 128>(rb1, S.b[buf ^ 1], tid);
+            if (want_csum) bf_colsum<AK, WM>(ra1, csum);
 #pragma unroll
             for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
 #pragma unroll
@@ -435,7 +442,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], float& csum, const
 }
 
 template <bool AK, bool BK, int MI, bool EDGE = false>
-__device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
+__device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], f32x4& csum, const bool want_csum,
                                           const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                           int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage& S) {
     TileLoader<AK, 64 * MI, true> la;
@@ -468,11 +475,12 @@ template <> struct TileMem<true> {
     BfStage st;
 };
 template <bool AK, bool BK, int MI, bool EDGE, bool BF>
-__device__ inline void gemm_accumulate_any(f32x16 (&acc)[MI][2], float& csum, const bool want_csum,
+__device__ inline void gemm_accumulate_any(f32x16 (&acc)[MI][2], float& csum, f32x4& csum4, const bool want_csum,
                                            const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                            int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
                                            TileMem<BF>& mem) {
-    if constexpr (BF) gemm_accumulate_bf<AK, BK, MI, EDGE>(acc, csum, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.st);
+    // csum (fp32 pipeline: one column, half the k rows per thread) / csum4 (bf16 pipeline: see bf_colsum)
+    if constexpr (BF) gemm_accumulate_bf<AK, BK, MI, EDGE>(acc, csum4, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.st);
     else gemm_accumulate<AK, BK, MI, EDGE>(acc, csum, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.As, mem.Bs);
 }
 
