@@ -738,18 +738,18 @@ class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p):
         x = x.contiguous()
-        out, mask = torch.empty_like(x), torch.empty_like(x)
-        call('xps_dropout_f32', _ptr(x), _ptr(out), _ptr(mask), x.numel(), float(p), next_dropout_seed(), _stream())
-        ctx.save_for_backward(mask)
-        ctx.scale = 1.0 / (1.0 - p)
+        out = torch.empty_like(x)
+        # no mask tensor: the decisions are a pure function of (seed, element index); the backward pass regenerates
+        # them with the same call on the incoming gradient (one pass less over a (T', B, 2H) tensor each way)
+        ctx.seed, ctx.p = next_dropout_seed(), float(p)
+        call('xps_dropout_f32', _ptr(x), _ptr(out), None, x.numel(), ctx.p, ctx.seed, _stream())
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (mask,) = ctx.saved_tensors
         dout = dout.contiguous()
         dx = torch.empty_like(dout)
-        call('xps_mask_scale_f32', _ptr(dout), _ptr(mask), ctx.scale, _ptr(dx), dout.numel(), _stream())
+        call('xps_dropout_f32', _ptr(dout), _ptr(dx), None, dout.numel(), ctx.p, ctx.seed, _stream())
         return dx, None
 
 

@@ -228,7 +228,9 @@ int xps_next_token(const float* logits, int n_classes, const int64_t* teacher, i
                    const int32_t* use_teacher, int64_t* next, int B, void* stream);
 /* Inverted dropout with a counter-based generator (no mask round trip through torch's RNG kernels):
  * mask[i] = (u_i >= p) in {0,1}, u_i a function of (seed, i) only;  if x != NULL also
- * out[i] = x[i] * mask[i] / (1 - p) in the same pass.  The backward is xps_mask_scale_f32.          */
+ * out[i] = x[i] * mask[i] / (1 - p) in the same pass.  mask may be NULL when x is given: the backward pass then
+ * regenerates the decisions by the same call on the incoming gradient (same seed), no mask tensor exists;
+ * with a stored mask the backward is xps_mask_scale_f32.                                                 */
 int xps_dropout_f32(const float* x, float* out, float* mask, int64_t n, float p, uint64_t seed, void* stream);
 /* out = x * mask * scale */
 int xps_mask_scale_f32(const float* x, const float* mask, float scale, float* out, int64_t n, void* stream);
