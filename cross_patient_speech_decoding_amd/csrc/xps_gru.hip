@@ -861,10 +861,10 @@ struct GruStepFwd {
     int vecA, vecB;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
     using namespace xps_tile;
-    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;        // fp32 k-major tiles or the bf16 split image
     const int dir = blockIdx.z, H = p.H, B = p.B, T = p.T;
     const int t = (dir == 0) ? p.s : T - 1 - p.s;
     const int slot_prev = (dir == 0) ? t : t + 2;
@@ -884,8 +884,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
     {
         // gemm_accumulate works on a (MI x 2) grid of 32x32 tiles per wave (64 x 64); here a wave owns
         // 32 trials x (3 gates x 32 units), so the k pipeline is restated for that shape.
-        using LA = TileLoader<true, 128>;
-        using LB = TileLoader<true, 128>;
+        using LA = TileLoader<true, 128, BF>;
+        using LB = TileLoader<true, 128, BF>;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         LA la; LB lb;
         la.init(hprev, ra, m0, B, H, tid, p.vecA);
@@ -907,8 +907,16 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
             la.load(ra1, hprev, ra, m0, B, BKT, H, tid, p.vecA);
             lb.load(rb1, Wb, rb, 0, 96, BKT, H, tid, p.vecB);
         }
-        la.store(ra0, As[0], tid);
-        lb.store(rb0, Bs[0], tid);
+        auto stage = [&](const f32x4 (&va)[LA::NV], const f32x4 (&vb)[LB::NV], int buf) {
+            if constexpr (BF) {
+                bf_store<true, 128>(va, mem.st.a[buf], tid);
+                bf_store<true, 128>(vb, mem.st.b[buf], tid);
+            } else {
+                la.store(va, mem.As[buf], tid);
+                lb.store(vb, mem.Bs[buf], tid);
+            }
+        };
+        stage(ra0, rb0, 0);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int buf = kt & 1;
@@ -916,16 +924,28 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
                 la.load(ra0, hprev, ra, m0, B, (kt + 2) * BKT, H, tid, p.vecA);
                 lb.load(rb0, Wb, rb, 0, 96, (kt + 2) * BKT, H, tid, p.vecB);
             }
+            if constexpr (BF) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&mem.st.a[buf].hi[wave * 32 + li][lk * 8]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&mem.st.a[buf].lo[wave * 32 + li][lk * 8]);
 #pragma unroll
-            for (int kk = 0; kk < BKT; kk += 2) {
-                const float a = As[buf][kk + lk][wave * 32 + li];
+                for (int g = 0; g < 3; ++g) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&mem.st.b[buf].hi[g * 32 + li][lk * 8]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&mem.st.b[buf].lo[g * 32 + li][lk * 8]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[g], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[buf][kk + lk][g * 32 + li], acc[g], 0, 0, 0);
+                for (int kk = 0; kk < BKT; kk += 2) {
+                    const float a = mem.As[buf][kk + lk][wave * 32 + li];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, mem.Bs[buf][kk + lk][g * 32 + li], acc[g], 0, 0, 0);
+                }
             }
             if (kt + 1 < nkt) {
-                la.store(ra1, As[buf ^ 1], tid);
-                lb.store(rb1, Bs[buf ^ 1], tid);
+                stage(ra1, rb1, buf ^ 1);
 #pragma unroll
                 for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
 #pragma unroll
@@ -993,10 +1013,10 @@ struct GruStepBwd {
     int vecA1, vecA2, vecB;
 };
 
+template <bool BF>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruStepBwd p) {
     using namespace xps_tile;
-    __shared__ __attribute__((aligned(16))) float As[2][BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
     const int dir = blockIdx.z, H = p.H, B = p.B, T = p.T;
     const int ldy = p.ndir * H;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 128;
@@ -1013,9 +1033,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruStepBwd p) {
         RowMap r2; r2.gs = 0; r2.ld = H; r2.rpg = 1 << 30;
         RowMap rb; rb.gs = 0; rb.ld = H; rb.rpg = 1 << 30;
         float nocs = 0.f;
+        f32x4 nocs4 = {0.f, 0.f, 0.f, 0.f};
         const float* W = p.w_hh[dir];
-        gemm_accumulate<true, false, 1>(acc, nocs, false, A1, r1, W, rb, B, H, 2 * H, m0, n0, 0, 2 * H, p.vecA1, p.vecB, As, Bs);
-        gemm_accumulate<true, false, 1>(acc, nocs, false, A2, r2, W + (long long)2 * H * H, rb, B, H, H, m0, n0, 0, H, p.vecA2, p.vecB, As, Bs);
+        gemm_accumulate_any<true, false, 1, false, BF>(acc, nocs, nocs4, false, A1, r1, W, rb, B, H, 2 * H, m0, n0, 0, 2 * H, p.vecA1, p.vecB, mem);
+        gemm_accumulate_any<true, false, 1, false, BF>(acc, nocs, nocs4, false, A2, r2, W + (long long)2 * H * H, rb, B, H, H, m0, n0, 0, H, p.vecA2, p.vecB, mem);
     }
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
     const int li = lane & 31, lk = lane >> 5;
@@ -1126,7 +1147,8 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
         dim3 sgrid(cdiv(H, 32), cdiv(B, 128), ndir);
         for (int s = 0; s < T; ++s) {
             q.s = s;
-            hipLaunchKernelGGL(gru_step_fwd_kernel, sgrid, dim3(256), 0, st, q);
+            if (xps_internal_gemm_mode() == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<true>, sgrid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(gru_step_fwd_kernel<false>, sgrid, dim3(256), 0, st, q);
         }
         XPS_CHECK_LAUNCH();
         return XPS_OK;
@@ -1205,12 +1227,14 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
         for (int s = T - 1; s >= 0; --s) {
             q.s = s; q.first = (s == T - 1); q.final = 0;
             q.keep_in = keep[pp]; q.keep_out = keep[pp ^ 1];
-            hipLaunchKernelGGL(gru_step_bwd_kernel, sgrid, dim3(256), 0, st, q);
+            if (xps_internal_gemm_mode() == 1) hipLaunchKernelGGL(gru_step_bwd_kernel<true>, sgrid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(gru_step_bwd_kernel<false>, sgrid, dim3(256), 0, st, q);
             pp ^= 1;
         }
         if (dh0) {
             q.s = 0; q.first = 0; q.final = 1; q.keep_in = keep[pp]; q.keep_out = keep[pp ^ 1];
-            hipLaunchKernelGGL(gru_step_bwd_kernel, sgrid, dim3(256), 0, st, q);
+            if (xps_internal_gemm_mode() == 1) hipLaunchKernelGGL(gru_step_bwd_kernel<true>, sgrid, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(gru_step_bwd_kernel<false>, sgrid, dim3(256), 0, st, q);
         }
         XPS_CHECK_LAUNCH();
         return XPS_OK;
