@@ -172,8 +172,35 @@ struct TnGroup {
     TnProb p[TN_MAXP];
     int n;
     int total_blocks;
-    long long total_out;      // sum of M * (N + has_colsum)
+    long long total_out;      // reduce outputs: sum of tiles * TN_TILE (padded tiles) + M column sums
 };
+
+constexpr int TN_TILE = BM * BN;       // floats of one output tile in a slab
+// floats of one split's slab: the tiles, then the column sums (padded so that every slab stays 16-byte aligned)
+__host__ __device__ inline long long tn_split_stride(long long ntiles, int M, bool has_colsum) {
+    return ntiles * TN_TILE + (has_colsum ? ((M + 3) & ~3) : 0);
+}
+// slab tile in register order: [wave 4][i 2][j 2][q 4][lane 64][c 4], accumulator register = 4 q + c
+__device__ inline void slab_store(const f32x16 (&acc)[2][2], float* __restrict__ tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* base = tile + wave * 4096 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + ((i * 2 + j) * 4 + q) * 256));
+            }
+}
+// (row, col) inside the 128 x 128 tile of slab element e (inverse of slab_store + the MFMA C layout)
+__device__ inline void slab_decode(int e, int& row, int& col) {
+    const int wave = e >> 12, ij = (e >> 10) & 3, q = (e >> 8) & 3, lane = (e >> 2) & 63, c = e & 3;
+    const int reg = 4 * q + c, li = lane & 31, lk = lane >> 5;
+    row = (wave >> 1) * 64 + (ij >> 1) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lk;
+    col = (wave & 1) * 64 + (ij & 1) * 32 + li;
+}
 
 template <bool EDGE, bool BF = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
@@ -186,23 +213,25 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
         if (lid >= g.p[i].block_start) pi = i;
     const TnProb& P = g.p[pi];
     const int local = lid - P.block_start;
-    const int Nout = P.N + (P.colsum ? 1 : 0);          // slab row = N products + 1 column sum
     const int tiles_m = (P.M + BM - 1) / BM;
-    const int tile = local % (tiles_m * P.tiles_n), z = local / (tiles_m * P.tiles_n);
+    const int ntiles = tiles_m * P.tiles_n;
+    const int tile = local % ntiles, z = local / ntiles;
     const int tm = tile / P.tiles_n, tn = tile % P.tiles_n;
     const int kbeg = z * P.kchunk;
     const int kend = min(P.K, kbeg + P.kchunk);
-    RowMap rs;
-    rs.gs = 0; rs.ld = P.N; rs.rpg = 1 << 30;
-    float* slab = ws + P.slab_off + (long long)z * P.M * Nout;
-    float* cs = (P.colsum && tn == 0) ? slab + (long long)P.M * P.N + tm * BM : nullptr;
+    // One split's slab: [tile][TN_TILE floats in REGISTER order] then [M column sums].  The slab is private scratch, so a
+    // tile is written exactly as the accumulators sit in the lanes (16-byte stores, 4 per 32x32 MFMA tile instead of 16
+    // 4-byte ones: the store phase of a block was ~24 % of its time); the reduce pass undoes the permutation.
+    const long long split_stride = tn_split_stride(ntiles, P.M, P.colsum != nullptr);
+    float* slab = ws + P.slab_off + (long long)z * split_stride;
+    float* cs = (P.colsum && tn == 0) ? slab + (long long)ntiles * TN_TILE + tm * BM : nullptr;
     f32x16 acc[2][2];
     zero_acc<2>(acc);
     float csum = 0.f;
     f32x4 csum4 = {0.f, 0.f, 0.f, 0.f};
     gemm_accumulate_any<false, false, 2, EDGE, BF>(acc, csum, csum4, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
                                                    kbeg, kend, P.vecA, P.vecB, mem);
-    gemm_store<2>(acc, slab, rs, nullptr, P.M, P.N, tm * BM, tn * BN, 0);
+    slab_store(acc, slab + (long long)tile * TN_TILE);
     if (BF && cs) {
         // bf16 pipeline: thread (kq = tid % 8, x group = tid / 8) holds the sums of columns 4 xg .. 4 xg + 3 over its k rows;
         // the 8 kq lanes are adjacent: fold them with a fixed xor tree, lane kq = 0 writes
@@ -250,28 +279,43 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
     __shared__ float part[4][RED_OUT];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long idx = (long long)blockIdx.x * RED_OUT + l;
-    const bool live = idx < g.total_out;
+    bool live = idx < g.total_out;
     int pi = 0;
     long long base = 0;
     if (live) {
 #pragma unroll 1
         for (int i = 0; i < g.n; ++i) {
-            const long long sz = (long long)g.p[i].M * (g.p[i].N + (g.p[i].colsum ? 1 : 0));
+            const long long sz = tn_split_stride((long long)((g.p[i].M + BM - 1) / BM) * g.p[i].tiles_n, g.p[i].M, g.p[i].colsum != nullptr);
             if (idx < base + sz) { pi = i; break; }
             base += sz;
         }
     }
     const TnProb& P = g.p[pi];
-    const int Nout = P.N + (P.colsum ? 1 : 0);
-    const long long e = idx - base;                       // [0, M*N): products, then M column sums
-    part[w][l] = live ? slab_sum(ws + P.slab_off + e, (long long)P.M * Nout, P.splits, w) : 0.f;
+    const long long tile_floats = (long long)((P.M + BM - 1) / BM) * P.tiles_n * TN_TILE;
+    const long long split_stride = tn_split_stride(tile_floats / TN_TILE, P.M, P.colsum != nullptr);
+    const long long e = idx - base;                       // [0, tile_floats): products in slab order, then M column sums
+    float* dst = nullptr;
+    bool is_cs = false;
+    if (live) {
+        if (e < tile_floats) {
+            const int tile = (int)(e / TN_TILE);
+            int r, c;
+            slab_decode((int)(e % TN_TILE), r, c);
+            const int row = (tile / P.tiles_n) * BM + r, col = (tile % P.tiles_n) * BN + c;
+            live = row < P.M && col < P.N;                // padding of edge tiles
+            if (live) dst = P.C + P.rc.off(row) + col;
+        } else {
+            is_cs = true;
+            live = e - tile_floats < P.M;                 // alignment padding behind the column sums
+            if (live) dst = P.colsum + (e - tile_floats);
+        }
+    }
+    part[w][l] = live ? slab_sum(ws + P.slab_off + e, split_stride, P.splits, w) : 0.f;
     __syncthreads();
     if (w == 0 && live) {
         float s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
-        const long long mn = (long long)P.M * P.N;
-        float* dst = (e < mn) ? (P.C + P.rc.off((int)(e / P.N)) + (int)(e % P.N)) : (P.colsum + (e - mn));
         // accumulate bit 0: products AND column sums add to their destinations; bit 1: the column sums only
-        if ((P.accumulate & 1) || ((P.accumulate & 2) && e >= mn)) s += *dst;
+        if ((P.accumulate & 1) || ((P.accumulate & 2) && is_cs)) s += *dst;
         *dst = s;
     }
 }
@@ -506,8 +550,8 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         P.A = q.A; P.B = q.B; P.C = q.C; P.colsum = q.colsum_a;
         P.ra = to_rowmap(&q.ra); P.rb = to_rowmap(&q.rb); P.rc = to_rowmap(&q.rc);
         P.M = q.M; P.N = q.N; P.K = q.K; P.accumulate = q.accumulate;
-        const int Nout = q.N + (q.colsum_a ? 1 : 0);
         const int tiles = cdiv(q.M, BM) * cdiv(q.N, BN);
+        const long long split_stride = tn_split_stride(tiles, q.M, q.colsum_a != nullptr);   // see gemm_tn_grouped_kernel
         // share the block budget among the problems in proportion to their tiles; >= 64 rows per split
         int want = (int)((target_blocks * (long long)tiles / (tiles_total > 0 ? tiles_total : 1) + tiles - 1) / tiles);
         int maxs = cdiv(q.K > 0 ? q.K : 1, 64);
@@ -523,8 +567,8 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         P.block_start = blocks;
         P.pad_ = 0;
         blocks += tiles * sp;
-        off += (long long)sp * q.M * Nout;
-        out += (long long)q.M * Nout;
+        off += (long long)sp * split_stride;
+        out += split_stride;
     }
     g.total_blocks = blocks;
     g.total_out = out;
