@@ -114,10 +114,10 @@ def capture_dominant_launch(step_fn):
         holder['tensors'] = tensors
         return orig_launch(fn, device, tensors, direct)
 
-    def group(problems, device):
+    def group(problems, device, stream=None):
         fl = sum(2.0 * q.M * q.N * q.K for q in problems)
         seen.append((fl, list(problems), holder['tensors']))
-        return orig_group(problems, device)
+        return orig_group(problems, device, stream)
     XF.gemm_tn_grouped, XF._launch_weight_grads = group, launch
     try:
         step_fn()

@@ -107,14 +107,20 @@ def tn_problem(A, B, out, M, N, K, ra=None, rb=None, rc=None, colsum_out=None, a
                      rc or rowmap(N), M, N, K, int(bool(accumulate)) | (2 if accumulate_colsum else 0))
 
 
-def gemm_tn_grouped(problems, device):
-    """All problems in ONE split-K launch + ONE reduce launch (deterministic)."""
+def gemm_tn_grouped(problems, device, stream=None):
+    """All problems in ONE split-K launch + ONE reduce launch (deterministic).  stream: raw HIP stream handle to launch
+    on (default: torch's current stream); returns the workspace tensors (the caller of a foreign-stream launch keeps them
+    alive until that stream has been joined)."""
+    st = _stream() if stream is None else stream
+    keep = []
     for i in range(0, len(problems), 12):
         chunk = problems[i:i + 12]
         arr = (TnProblem * len(chunk))(*chunk)
         nbytes = lib().xps_gemm_tn_grouped_f32_workspace(arr, len(chunk))
         ws = _ws(nbytes, device)
-        call('xps_gemm_tn_grouped_f32', arr, len(chunk), _ptr(ws), nbytes, _stream())
+        call('xps_gemm_tn_grouped_f32', arr, len(chunk), _ptr(ws), nbytes, st)
+        keep.append(ws)
+    return keep
 
 
 # Weight-gradient GEMMs are off the critical path of the backward pass (nothing downstream reads them until
@@ -138,27 +144,32 @@ def _low_priority_stream(idx):
     return torch.cuda.ExternalStream(handle.value, device=idx)
 
 
+_side_keep = []        # operands / workspaces of launches on the side stream: referenced until the main stream has joined
+
+
 def _join_side_streams():
     for dev_index in list(_side_pending):
         torch.cuda.current_stream(dev_index).wait_stream(_side_streams[dev_index])
     _side_pending.clear()
+    # everything the side stream read may be released now: later allocations are ordered behind the join on the main stream
+    _side_keep.clear()
 
 
 def _launch_weight_grads(fn, device, tensors, direct):
-    """fn() enqueues weight-gradient kernels reading `tensors`.  Runs it on the side stream when allowed."""
+    """fn(stream) enqueues weight-gradient kernels reading `tensors` on the raw HIP stream it is given (None: the current
+    stream) and returns the temporaries it allocated.  Runs it on the side stream when allowed.  The kernels take the
+    stream as a C-ABI argument, so torch's current stream is never switched (the context manager and one
+    record_stream per operand cost ~30 us of host time per call site; the operands are kept alive until the join)."""
     if not (OVERLAP_WEIGHT_GRADS and direct):
-        fn()
+        fn(None)
         return
     idx = device.index if device.index is not None else torch.cuda.current_device()
     side = _side_streams.get(idx)
     if side is None:
         side = _side_streams[idx] = _low_priority_stream(idx)
     side.wait_stream(torch.cuda.current_stream(idx))
-    with torch.cuda.stream(side):
-        fn()
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
+    keep = fn(side.cuda_stream)
+    _side_keep.append((tensors, keep))
     if idx not in _side_pending:
         if not _side_pending:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
@@ -242,7 +253,7 @@ class LinearFn(torch.autograd.Function):
                     db = torch.empty(N, dtype=_f32, device=dy.device)
                     acc_w, rw, rb = False, dw, db
             prob = [tn_problem(dy2, x2, dw, N, K, M, colsum_out=db, accumulate=acc_w)]
-            _launch_weight_grads(lambda: gemm_tn_grouped(prob, dy.device), dy.device, (dy2, x2),
+            _launch_weight_grads(lambda st: gemm_tn_grouped(prob, dy.device, st), dy.device, (dy2, x2),
                                  rw is None and (rb is None or not need_b))
             if not need_w:
                 rw = None
@@ -419,7 +430,7 @@ class GRULayerFn(torch.autograd.Function):
             probs.append(tn_problem(dgi[d], x, dw, 3 * H, In, T * B, colsum_out=db, accumulate=acc_w))
             rets_ih.append((rw, rb))
         direct = all(r[0] is None and r[1] is None for r in rets_ih + rets_hh)
-        _launch_weight_grads(lambda: gemm_tn_grouped(probs, dev), dev, (dgi, dghn, x, y_ext), direct)
+        _launch_weight_grads(lambda st: gemm_tn_grouped(probs, dev, st), dev, (dgi, dghn, x, y_ext), direct)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, In, dtype=_f32, device=dev)
@@ -642,7 +653,7 @@ class DecoderFn(torch.autograd.Function):
             tn_problem(dlogits, hnext, dwf, C, H, L * B, ra=rowmap(L * C, rpg=B, gs=C), rb=rowmap(H), rc=rowmap(H),
                        colsum_out=dbf, accumulate=acc_f),
         ]
-        _launch_weight_grads(lambda: gemm_tn_grouped(probs, dev), dev, (dgi, dghn, hs, dlogits),
+        _launch_weight_grads(lambda st: gemm_tn_grouped(probs, dev, st), dev, (dgi, dghn, hs, dlogits),
                              r_wh is None and r_bh is None and r_wf is None and r_bf is None)
         # d table[tok] += dgi over all (step, trial) rows
         dtable = torch.empty(ntok, 3 * H, dtype=_f32, device=dev)
