@@ -233,20 +233,16 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
                                                    kbeg, kend, P.vecA, P.vecB, mem);
     slab_store(acc, slab + (long long)tile * TN_TILE);
     if (BF && cs) {
-        // bf16 pipeline: thread (kq = tid % 8, x group = tid / 8) holds the sums of columns 4 xg .. 4 xg + 3 over its k rows;
-        // the 8 kq lanes are adjacent: fold them with a fixed xor tree, lane kq = 0 writes
-        using LA = TileLoader<false, 128, true>;
-        static_assert(LA::KQ == 8, "column-sum fold assumes 8 k groups per tile");
+        // bf16 pipeline: thread (k row = tid / 32, x group = tid % 32) holds the sums of columns 4 xg .. 4 xg + 3 over its
+        // k rows; lanes l and l + 32 of a wave share the x group, the four waves are folded through LDS in a fixed order
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        float* red = reinterpret_cast<float*>(&mem);
 #pragma unroll
-        for (int off = 1; off < LA::KQ; off <<= 1)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) csum4[j] += __shfl_xor(csum4[j], off);
-        const int tid = threadIdx.x, x4 = (tid / LA::KQ) * 4;
-        if (tid % LA::KQ == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (tm * BM + x4 + j < P.M) cs[x4 + j] = csum4[j];
-        }
+        for (int j = 0; j < 4; ++j) csum4[j] += __shfl_xor(csum4[j], 32);
+        __syncthreads();
+        if (lane < 32) *reinterpret_cast<f32x4*>(&red[wave * 128 + lane * 4]) = csum4;
+        __syncthreads();
+        if (tid < 128 && tm * BM + tid < P.M) cs[tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     } else if (cs) {                            // fold the two k-groups of the column sums through LDS
         const int tid = threadIdx.x;
         float* red = reinterpret_cast<float*>(&mem);
@@ -393,8 +389,7 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, MI_, EDGE_, BF_>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, \
                        bias, M, N, K, kchunk, 0LL, accumulate, vecA, vecB)
     const bool bf = bf_mode();
-    // the [k][m] A operand of the bf16 pipeline packs two k rows per thread only with 128-row tiles
-    if (use_small_tiles(M, N) && !(bf && !AK)) {
+    if (use_small_tiles(M, N)) {
         dim3 grid(cdiv(N, BN) * cdiv(M, 64));
         const bool edge = (M % 64) || (N % BN);
         if (bf) { if (edge) XPS_LAUNCH_GEMM(1, true, true); else XPS_LAUNCH_GEMM(1, false, true); }

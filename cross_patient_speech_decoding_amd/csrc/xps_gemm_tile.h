@@ -38,8 +38,7 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 }
 
 // Stages a (BKT x W) k-major tile of a matrix stored either [x][k] (KCONTIG) or [k][x]; W = 64 or 128.
-// BF: staging for the bf16 split-product pipeline (gemm_accumulate_bf): the [k][x] form hands every thread NV
-// CONSECUTIVE k rows of one 4-wide x group, so that the k-contiguous bf16 image can be written with packed stores.
+// BF: tag of the loaders used by the bf16 split-product pipeline (gemm_accumulate_bf); same geometry.
 template <bool KCONTIG, int W, bool BF = false>
 struct TileLoader {
     // KCONTIG : 16-byte vectors along k; thread -> (x = tid / KL (+ XR per pass), k4 = (tid % KL) * 4)
@@ -50,10 +49,11 @@ struct TileLoader {
     static constexpr int XL = W / 4;                    // !KCONTIG: lanes per k row
     static constexpr int KR = 256 / XL;                 // !KCONTIG: k rows per pass
     static constexpr int NV = KCONTIG ? W / XR : BKT / KR;
-    static constexpr int KQ = BKT / NV;                 // !KCONTIG, BF: k groups (of NV consecutive rows) per tile
-    // !KCONTIG thread map: k row of register r, 4-wide x group of the thread
-    __device__ static inline int krow(int tid, int r) { return BF ? (tid % KQ) * NV + r : tid / XL + KR * r; }
-    __device__ static inline int xgrp(int tid) { return BF ? tid / KQ : tid % XL; }
+    // !KCONTIG thread map: k row of register r, 4-wide x group of the thread (a k row is read by XL adjacent lanes:
+    // W * 4 contiguous bytes).  Both pipelines use it: the bf16 one keeps [k][x] operands un-transposed in LDS and reads
+    // the MFMA fragments with the transposing ds_read_b64_tr_b16 (bf_frag).
+    __device__ static inline int krow(int tid, int r) { return tid / XL + KR * r; }
+    __device__ static inline int xgrp(int tid) { return tid % XL; }
     const float* base[NV];
     long long xoff[NV];
     long long kstride, kgs;       // !KCONTIG: row stride inside a group / group stride of the k rows
@@ -313,9 +313,19 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int BFROW = 24;                                // shorts per LDS row (BKT = 16 used + 8 pad)
 static_assert(BKT == 16, "the bf16 pipeline maps one k-tile to one 32x32x16 MFMA step");
+constexpr int BFTROW = 160;                              // shorts per row of the [k][x] image: 128 + 32 pad (320 B: the four
+                                                         // k rows of a transposed read start 16 banks apart)
 struct BfTile {
-    __bf16 hi[128][BFROW];
-    __bf16 lo[128][BFROW];
+    union {
+        struct {                                         // [x][k] operands: row = x, 16 k-contiguous bf16 (+ pad)
+            __bf16 hi[128][BFROW];
+            __bf16 lo[128][BFROW];
+        };
+        struct {                                         // [k][x] operands: stored as they are loaded, row = k
+            __bf16 thi[BKT][BFTROW];
+            __bf16 tlo[BKT][BFTROW];
+        };
+    };
 };
 struct BfStage {                                         // what a kernel declares in LDS: 2 buffers x (A, B)
     BfTile a[2], b[2];
@@ -341,31 +351,46 @@ __device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::N
             *reinterpret_cast<bf16x4*>(&S.lo[x][k4]) = l;
         }
     } else {
-        // the thread holds k rows NV*kq .. NV*kq + NV-1 of x columns 4*xg .. 4*xg + 3: transpose in registers
-        constexpr int NV = L::NV;
-        const int k0 = (tid % L::KQ) * NV, x4 = (tid / L::KQ) * 4;
-        typedef __bf16 bfv __attribute__((ext_vector_type(NV > 1 ? NV : 2)));
+        // [k][x] operand: no transposition here — 8-byte stores of 4 x-consecutive bf16 into the k-row image (XL adjacent
+        // lanes fill one row: conflict-free); the MFMA fragments are gathered by the transposing LDS read (bf_frag)
+        const int x4 = (tid % L::XL) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (NV == 1) {
-                __bf16 a, b;
-                bf_split(v[0][j], a, b);
-                S.hi[x4 + j][k0] = a;
-                S.lo[x4 + j][k0] = b;
-            } else {
-                bfv h, l;
+        for (int r = 0; r < L::NV; ++r) {
+            const int k = tid / L::XL + L::KR * r;
+            bf16x4 h, l;
 #pragma unroll
-                for (int r = 0; r < NV; ++r) { __bf16 a, b; bf_split(v[r][j], a, b); h[r] = a; l[r] = b; }
-                *reinterpret_cast<bfv*>(&S.hi[x4 + j][k0]) = h;
-                *reinterpret_cast<bfv*>(&S.lo[x4 + j][k0]) = l;
-            }
+            for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+            *reinterpret_cast<bf16x4*>(&S.thi[k][x4]) = h;
+            *reinterpret_cast<bf16x4*>(&S.tlo[k][x4]) = l;
         }
+    }
+}
+
+// MFMA operand fragment (32x32x16: lane -> row x0 + (lane & 31), k = 8 (lane >> 5) + 0..7) of one staged tile.
+// [x][k] image: one ds_read_b128.  [k][x] image: two ds_read_b64_tr_b16 — per 16-lane group the hardware reads a block of
+// 4 k rows x 16 x columns and hands lane i column i (4 consecutive k of one x); lane 4q + p supplies the address of
+// row q, columns 4p .. 4p + 3.  Needs EXEC = all ones (no divergence around the k loop).
+template <bool KCONTIG>
+__device__ inline void bf_frag(const BfTile& S, int x0, int lane, bf16x8& fh, bf16x8& fl) {
+    if constexpr (KCONTIG) {
+        fh = *reinterpret_cast<const bf16x8*>(&S.hi[x0 + (lane & 31)][(lane >> 5) * 8]);
+        fl = *reinterpret_cast<const bf16x8*>(&S.lo[x0 + (lane & 31)][(lane >> 5) * 8]);
+    } else {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int k0 = 8 * (g >> 1) + q, c0 = x0 + (g & 1) * 16 + 4 * pp;
+        const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.thi[k0][c0]));
+        const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.thi[k0 + 4][c0]));
+        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.tlo[k0][c0]));
+        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.tlo[k0 + 4][c0]));
+        fh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        fl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
 // Column sums of the A operand (bias gradient of the TN form) from the staging REGISTERS, before the split: every k-tile
 // passes through them exactly once.  [k][x] form only: the thread's running sums are those of its 4 x columns over its
-// NV k rows; the KQ threads (adjacent lanes) that share the x group are folded by the kernel with lane shuffles.
+// NV k rows; the 256 / XL threads that share the x group are folded by the kernel (lane shuffle + LDS).
 template <bool KCONTIG, int W>
 __device__ inline void bf_colsum(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], f32x4& cs) {
     if constexpr (!KCONTIG) {           // (never requested for [x][k] operands)
@@ -410,15 +435,9 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
         {
             bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(&S.a[buf].hi[wm + i * 32 + li][lk * 8]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&S.a[buf].lo[wm + i * 32 + li][lk * 8]);
-            }
+            for (int i = 0; i < MI; ++i) bf_frag<AK>(S.a[buf], wm + i * 32, lane, ah[i], al[i]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(&S.b[buf].hi[wn + j * 32 + li][lk * 8]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&S.b[buf].lo[wn + j * 32 + li][lk * 8]);
-            }
+            for (int j = 0; j < 2; ++j) bf_frag<BK>(S.b[buf], wn + j * 32, lane, bh[j], bl[j]);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
