@@ -321,13 +321,15 @@ def main():
             'vs_baseline': None,
             # bf16x3: every fp32 operand split hi + lo in bf16, 3 bf16 MFMAs per product, fp32 accumulation and fp32 everywhere
             # else (results within 2e-6 of the fp32 reference goldens); fp32: fp32 MFMA
-            'dtype': 'bf16x3-split MFMA products, f32 accumulate' if precision == 'bf16x3' else 'f32',
+            'dtype': 'bf16x3' if precision == 'bf16x3' else 'f32',
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: single-patient seq2seq GRU, H=128, T=200 (T\'=20), C=64, F=100, '
                                    'enc 2x bi-GRU, dec 1x GRU, full-batch step of 2048 trials per GPU, '
                                    'dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW',
                        'trials_per_gpu': c['trials_per_gpu'], 'global_batch': c['trials_per_gpu'] * world,
-                       'parallelism': f'dp{world}', 'train_mflop_per_trial': round(fl / 1e6, 2)},
+                       'parallelism': f'dp{world}', 'train_mflop_per_trial': round(fl / 1e6, 2),
+                       'precision': ('bf16x3 = fp32 operands split hi + lo in bf16, 3 bf16 MFMAs per product, fp32 accumulate and '
+                                     'fp32 everywhere else' if precision == 'bf16x3' else 'fp32 MFMA')},
             'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
         }
         if not explore:
