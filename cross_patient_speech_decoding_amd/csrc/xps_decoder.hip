@@ -1,6 +1,7 @@
 // Fused autoregressive decoder (reference nn_models/models.py:285-299 loop around DecoderRNN
 // :758-761): for every decode step  embedding/input-projection gather -> GRU cell (W_hh resident
-// in VGPRs, h W_hh^T on the f32 MFMA) -> Linear(H, n_classes) -> argmax-or-teacher next token,
+// in VGPRs, h W_hh^T on the f32 MFMA or, in the default precision, as bf16 split products) -> Linear(H, n_classes) ->
+// argmax-or-teacher next token,
 // ALL steps in ONE persistent launch: no host round trip per step (the reference syncs on
 // `torch.rand(1).item()` and `argmax` every step) and no per-step kernel boundaries.
 //
@@ -9,6 +10,10 @@
 // encoder kernels in xps_gru.hip).  One-layer decoders with H = 64 or 128 only; other shapes go
 // through the composed path (gather + xps_gru_seq + GEMM).
 #include "xps_common.h"
+#include "xps_gemm_tile.h"
+using xps_tile::bf16x4;
+using xps_tile::bf16x8;
+using xps_tile::bf_split;
 
 namespace {
 
@@ -36,10 +41,13 @@ struct DecFwdParams {
     int B, C, L, ntok, start_token;
 };
 
-template <int H>
+// BF: the recurrent product on the bf16 matrix pipe with split operands, as in the GRU sequence kernels (xps_gru.hip)
+template <int H, bool BF>
 __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
     constexpr int NT = H / 16, TPW = NT / 4, NC = H / 16, LDH = H + 4;
+    constexpr int NCB = H / 32, LDB = H + 8;
     __shared__ __attribute__((aligned(16))) float hs_l[2][DBM][LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 hsb[BF ? 2 : 1][2][BF ? DBM : 1][BF ? LDB : 8];   // [buffer][hi, lo][trial][k]
     __shared__ float wfc[MAXC][H + 1];          // +1: the FC dot products read a column of classes
     __shared__ float lg[DBM][MAXC];
     __shared__ int tok_l[DBM];
@@ -51,7 +59,8 @@ __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
     const bool live = b < B;
     const int bc = live ? b : B - 1;
 
-    float w[TPW][3][NC][4];
+    float w[BF ? 1 : TPW][3][NC][4];
+    bf16x8 wh[BF ? TPW : 1][3][NCB], wl[BF ? TPW : 1][3][NCB];
     float4 bias[TPW][3];
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt)
@@ -59,10 +68,24 @@ __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
         for (int g = 0; g < 3; ++g) {
             const int j0 = (wave + 4 * tt) * 16;
             bias[tt][g] = *reinterpret_cast<const float4*>(p.b_hh + g * H + j0 + 4 * kq);
+            if constexpr (BF) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(p.w_hh + (long long)(g * H + j0 + n) * H + 16 * c + 4 * kq);
-                w[tt][g][c][0] = v.x; w[tt][g][c][1] = v.y; w[tt][g][c][2] = v.z; w[tt][g][c][3] = v.w;
+                for (int c = 0; c < NCB; ++c) {
+                    const float* wp = p.w_hh + (long long)(g * H + j0 + n) * H + 32 * c + 8 * kq;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(wp), v1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        __bf16 a, b;
+                        bf_split(v0[j], a, b); wh[tt][g][c][j] = a; wl[tt][g][c][j] = b;
+                        bf_split(v1[j], a, b); wh[tt][g][c][4 + j] = a; wl[tt][g][c][4 + j] = b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(p.w_hh + (long long)(g * H + j0 + n) * H + 16 * c + 4 * kq);
+                    w[tt][g][c][0] = v.x; w[tt][g][c][1] = v.y; w[tt][g][c][2] = v.z; w[tt][g][c][3] = v.w;
+                }
             }
         }
     for (int i = tid; i < C * H; i += 256) wfc[i / H][i % H] = p.w_fc[i];
@@ -78,6 +101,16 @@ __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
         }
     }
     __syncthreads();
+    if constexpr (BF) {
+        for (int i = tid; i < DBM * H; i += 256) {
+            const int r = i / H, k = i % H;
+            __bf16 a, b;
+            bf_split(hs_l[0][r][k], a, b);
+            hsb[0][0][r][k] = a; hsb[0][1][r][k] = b;
+            hsb[1][0][r][k] = (__bf16)0.f; hsb[1][1][r][k] = (__bf16)0.f;
+        }
+        __syncthreads();
+    }
 
     for (int s = 0; s < L; ++s) {
         const int cur = s & 1;
@@ -96,6 +129,21 @@ __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
         for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const bf16x8 bh8 = *reinterpret_cast<const bf16x8*>(&hsb[cur][0][n][32 * c + 8 * kq]);
+                const bf16x8 bl8 = *reinterpret_cast<const bf16x8*>(&hsb[cur][1][n][32 * c + 8 * kq]);
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[tt][g][c], bh8, acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][g][c], bl8, acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][g][c], bh8, acc[tt][g], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float4 a4 = *reinterpret_cast<const float4*>(&hs_l[cur][n][16 * c + 4 * kq]);
@@ -106,6 +154,7 @@ __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
                         acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tt][g][c][e], g4(a4, e), acc[tt][g], 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
@@ -123,6 +172,13 @@ __global__ __launch_bounds__(256, 1) void decoder_fwd_kernel(DecFwdParams p) {
             }
             const float4 h4 = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(&hs_l[cur ^ 1][n][j]) = h4;
+            if constexpr (BF) {
+                bf16x4 sh, sl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __bf16 a, b; bf_split(o[i], a, b); sh[i] = a; sl[i] = b; }
+                *reinterpret_cast<bf16x4*>(&hsb[cur ^ 1][0][n][j]) = sh;
+                *reinterpret_cast<bf16x4*>(&hsb[cur ^ 1][1][n][j]) = sl;
+            }
             if (live) {
                 *reinterpret_cast<float4*>(p.hs + ((long long)(s + 1) * B + b) * H + j) = h4;
                 if (p.saved) {
@@ -175,11 +231,13 @@ struct DecBwdParams {
     int B, C, L;
 };
 
-template <int H>
+template <int H, bool BF>
 __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdParams p) {
     constexpr int NT = H / 16, TPW = NT / 4, NC = 3 * H / 16, LDG = 3 * H + 4, LDC = H + 4;
+    constexpr int NCB = 3 * H / 32, LDGB = 3 * H + 8;
     constexpr int H4 = H / 4, GPT = DBM * H4 / 256;
-    __shared__ __attribute__((aligned(16))) float G[DBM][LDG];
+    __shared__ __attribute__((aligned(16))) float G[BF ? 1 : DBM][BF ? 4 : LDG];
+    __shared__ __attribute__((aligned(16))) __bf16 Gb[2][BF ? DBM : 1][BF ? LDGB : 8];      // BF: [hi, lo][trial][k]
     __shared__ __attribute__((aligned(16))) float Cy[DBM][LDC];
     __shared__ __attribute__((aligned(16))) float wfc[MAXC][H];
     __shared__ float dl[DBM][MAXC];
@@ -188,18 +246,37 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdParams p) {
     const int b0 = blockIdx.x * DBM;
     const int B = p.B, C = p.C, L = p.L;
 
-    float w[TPW][NC][4];
+    float w[BF ? 1 : TPW][NC][4];
+    bf16x8 wh[BF ? TPW : 1][NCB], wl[BF ? TPW : 1][NCB];
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         const int j = (wave + 4 * tt) * 16 + n;
+        if constexpr (BF) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(p.w_hh_t + (long long)j * 3 * H + 16 * c + 4 * kq);
-            w[tt][c][0] = v.x; w[tt][c][1] = v.y; w[tt][c][2] = v.z; w[tt][c][3] = v.w;
+            for (int c = 0; c < NCB; ++c) {
+                const float* wp = p.w_hh_t + (long long)j * 3 * H + 32 * c + 8 * kq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(wp), v1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, b;
+                    bf_split(v0[e], a, b); wh[tt][c][e] = a; wl[tt][c][e] = b;
+                    bf_split(v1[e], a, b); wh[tt][c][4 + e] = a; wl[tt][c][4 + e] = b;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(p.w_hh_t + (long long)j * 3 * H + 16 * c + 4 * kq);
+                w[tt][c][0] = v.x; w[tt][c][1] = v.y; w[tt][c][2] = v.z; w[tt][c][3] = v.w;
+            }
         }
     }
     for (int i = tid; i < C * H; i += 256) wfc[i / H][i % H] = p.w_fc[i];
-    for (int i = tid; i < DBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
+    if constexpr (BF) {
+        for (int i = tid; i < 2 * DBM * LDGB; i += 256) (&Gb[0][0][0])[i] = (__bf16)0.f;
+    } else {
+        for (int i = tid; i < DBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
+    }
     for (int i = tid; i < DBM * LDC; i += 256) (&Cy[0][0])[i] = 0.f;
     __syncthreads();
 
@@ -252,9 +329,23 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdParams p) {
                 *reinterpret_cast<float4*>(p.dgi + o + 2 * H + j) = make_float4(o_dan[0], o_dan[1], o_dan[2], o_dan[3]);
                 *reinterpret_cast<float4*>(p.dghn + ((long long)s * B + b) * H + j) = danr;
             }
-            *reinterpret_cast<float4*>(&G[r][j]) = dar;
-            *reinterpret_cast<float4*>(&G[r][H + j]) = daz;
-            *reinterpret_cast<float4*>(&G[r][2 * H + j]) = danr;
+            if constexpr (BF) {
+                auto put = [&](const float4& v, int col) {
+                    bf16x4 sh, sl;
+                    __bf16 a, b;
+                    bf_split(v.x, a, b); sh[0] = a; sl[0] = b;
+                    bf_split(v.y, a, b); sh[1] = a; sl[1] = b;
+                    bf_split(v.z, a, b); sh[2] = a; sl[2] = b;
+                    bf_split(v.w, a, b); sh[3] = a; sl[3] = b;
+                    *reinterpret_cast<bf16x4*>(&Gb[0][r][col]) = sh;
+                    *reinterpret_cast<bf16x4*>(&Gb[1][r][col]) = sl;
+                };
+                put(dar, j); put(daz, H + j); put(danr, 2 * H + j);
+            } else {
+                *reinterpret_cast<float4*>(&G[r][j]) = dar;
+                *reinterpret_cast<float4*>(&G[r][H + j]) = daz;
+                *reinterpret_cast<float4*>(&G[r][2 * H + j]) = danr;
+            }
             *reinterpret_cast<float4*>(&Cy[r][j]) = keep;
         }
         __syncthreads();
@@ -264,6 +355,19 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdParams p) {
             const float4 c4 = *reinterpret_cast<const float4*>(&Cy[n][(wave + 4 * tt) * 16 + 4 * kq]);
             acc[tt] = (f32x4){c4.x, c4.y, c4.z, c4.w};
         }
+        if constexpr (BF) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const bf16x8 bh8 = *reinterpret_cast<const bf16x8*>(&Gb[0][n][32 * c + 8 * kq]);
+                const bf16x8 bl8 = *reinterpret_cast<const bf16x8*>(&Gb[1][n][32 * c + 8 * kq]);
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) {
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[tt][c], bh8, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][c], bl8, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[tt][c], bh8, acc[tt], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float4 a4 = *reinterpret_cast<const float4*>(&G[n][16 * c + 4 * kq]);
@@ -272,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdParams p) {
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt)
                     acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tt][c][e], g4(a4, e), acc[tt], 0, 0, 0);
+        }
         }
         const bool live = b0 + n < B;
 #pragma unroll
@@ -310,8 +415,11 @@ extern "C" int xps_decoder_fwd_f32(const float* table, const float* w_hh, const 
     p.logits = logits; p.tokens = (long long*)tokens; p.hs = hs; p.saved = saved;
     p.B = B; p.C = C; p.L = L; p.ntok = ntok; p.start_token = start_token;
     dim3 grid(cdiv(B, DBM));
-    if (H == 128) hipLaunchKernelGGL(decoder_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(decoder_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const bool bf = xps_internal_gemm_mode() == 1;
+    if (H == 128 && bf) hipLaunchKernelGGL((decoder_fwd_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (H == 128) hipLaunchKernelGGL((decoder_fwd_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (bf) hipLaunchKernelGGL((decoder_fwd_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((decoder_fwd_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
@@ -328,8 +436,11 @@ extern "C" int xps_decoder_bwd_f32(const float* dlogits, const float* hs, const 
     p.dlogits = dlogits; p.hs = hs; p.saved = saved; p.w_hh_t = w_hh_t; p.w_fc = w_fc;
     p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0; p.B = B; p.C = C; p.L = L;
     dim3 grid(cdiv(B, DBM));
-    if (H == 128) hipLaunchKernelGGL(decoder_bwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(decoder_bwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const bool bf = xps_internal_gemm_mode() == 1;
+    if (H == 128 && bf) hipLaunchKernelGGL((decoder_bwd_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (H == 128) hipLaunchKernelGGL((decoder_bwd_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (bf) hipLaunchKernelGGL((decoder_bwd_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((decoder_bwd_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
