@@ -27,6 +27,10 @@ using xps_tile::bf_split;
 namespace {
 
 constexpr int GBM = 16;   // trials per workgroup
+#ifndef XPS_GRU_BF_WAVES
+#define XPS_GRU_BF_WAVES 8
+#endif
+constexpr int GRU_BF_WAVES = XPS_GRU_BF_WAVES;   // waves per workgroup of the H = 128 bf16 recurrence kernels
 
 struct GruFwdParams {
     const float* gi;
@@ -390,9 +394,13 @@ __device__ unsigned long long g_stamp[4096 * 8];
 // BF: the recurrent product h W_hh^T runs on the bf16 matrix pipe with split operands (W_hh split once into hi/lo
 // register fragments, h split when a step writes it to LDS; three v_mfma_f32_16x16x32_bf16 per product, see
 // xps_gemm_tile.h): the MFMA phase of a step shrinks from 192 x 32 to 72 x 16 cycles.
-template <int H, bool BF = false>
-__global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p) {
-    constexpr int NT = H / 16, TPW = NT / 4, NC = H / 16, LDH = H + 4;
+// NW waves per workgroup (4 or 8): with 8, every SIMD holds two waves of the workgroup (each owning one 16-unit tile and half
+// the W_hh fragments), which hides the LDS / MFMA-result / barrier latencies that a single wave per SIMD exposes.
+template <int H, bool BF = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void gru_fwd_resident_kernel(GruFwdParams p) {
+    constexpr int NTHR = NW * 64;
+    constexpr int NT = H / 16, TPW = NT / NW, NC = H / 16, LDH = H + 4;
+    static_assert(NT % NW == 0, "hidden tiles must divide among the waves");
     constexpr int NCB = H / 32, LDB = H + 8;   // BF: 32-wide k chunks; bf16 row stride (conflict-free b128 reads)
     constexpr int NST = TPW * 5;               // 16-byte stores per lane and step: h, r, z, n, q per tile
     __shared__ __attribute__((aligned(16))) float hs[2][GBM][LDH];
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
     for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            const int j0 = (wave + 4 * tt) * 16;
+            const int j0 = (wave + NW * tt) * 16;
             bias[tt][g] = *reinterpret_cast<const float4*>(bh + g * H + j0 + 4 * kq);
             if constexpr (BF) {
 #pragma unroll
@@ -444,11 +452,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
             }
         }
 
-    for (int i = tid; i < 2 * GBM * LDH; i += 256) (&hs[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * GBM * LDH; i += NTHR) (&hs[0][0][0])[i] = 0.f;
     __syncthreads();
     {
         const int slot_h0 = (dir == 0) ? 0 : T + 1, slot_other = (dir == 0) ? T + 1 : 0;
-        for (int i = tid; i < GBM * H; i += 256) {
+        for (int i = tid; i < GBM * H; i += NTHR) {
             const int r = i / H, k = i % H, bb = b0 + r;
             if (bb < B) {
                 const float v = p.h0 ? p.h0[((long long)dir * B + bb) * H + k] : 0.f;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
     }
     __syncthreads();
     if constexpr (BF) {
-        for (int i = tid; i < GBM * H; i += 256) {
+        for (int i = tid; i < GBM * H; i += NTHR) {
             const int r = i / H, k = i % H;
             __bf16 a, b;
             bf_split(hs[0][r][k], a, b);
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
     float* pend_sv = nullptr;
     auto issue_store = [&](int k) {            // k is a compile-time constant at every call site
         const int tt = k % TPW, what = k / TPW;
-        const int j = (wave + 4 * tt) * 16 + 4 * kq;
+        const int j = (wave + NW * tt) * 16 + 4 * kq;
         if (what == 0) *reinterpret_cast<float4*>(pend_y + j) = pend[k];
         else if (do_save) *reinterpret_cast<float4*>(pend_sv + (what - 1) * H + j) = pend[k];
     };
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
         for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                g_nxt[tt][g] = *reinterpret_cast<const float4*>(gp + g * H + (wave + 4 * tt) * 16 + 4 * kq);
+                g_nxt[tt][g] = *reinterpret_cast<const float4*>(gp + g * H + (wave + NW * tt) * 16 + 4 * kq);
     }
 #ifdef XPS_STAMP
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, acc_mfma = 0, acc_epi = 0, acc_store = 0, acc_bar = 0;
@@ -568,12 +576,12 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
             for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
-                    g_nxt[tt][g] = *reinterpret_cast<const float4*>(gp + g * H + (wave + 4 * tt) * 16 + 4 * kq);
+                    g_nxt[tt][g] = *reinterpret_cast<const float4*>(gp + g * H + (wave + NW * tt) * 16 + 4 * kq);
         }
         // gates: lane owns units j0 + 4*kq + {0..3} of trial b
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
-            const int j = (wave + 4 * tt) * 16 + 4 * kq;
+            const int j = (wave + NW * tt) * 16 + 4 * kq;
             const float4 hp = *reinterpret_cast<const float4*>(&hs[cur][n][j]);
             float o[4], r_[4], z_[4], n_[4], q_[4];
 #pragma unroll
@@ -628,11 +636,13 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_resident_kernel(GruFwdParams p
 #endif
 }
 
-template <int H, bool BF = false>
-__global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p) {
-    constexpr int NT = H / 16, TPW = NT / 4, NC = 3 * H / 16, LDG = 3 * H + 4, LDC = H + 4;
+template <int H, bool BF = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void gru_bwd_resident_kernel(GruBwdParams p) {
+    constexpr int NTHR = NW * 64;
+    constexpr int NT = H / 16, TPW = NT / NW, NC = 3 * H / 16, LDG = 3 * H + 4, LDC = H + 4;
+    static_assert(NT % NW == 0, "hidden tiles must divide among the waves");
     constexpr int NCB = 3 * H / 32, LDGB = 3 * H + 8;     // BF: 32-wide k chunks; bf16 row stride of the gate gradients
-    constexpr int H4 = H / 4, GPT = GBM * H4 / 256;       // float4 groups of the 16 x H tile per thread
+    constexpr int H4 = H / 4, GPT = GBM * H4 / NTHR;       // float4 groups of the 16 x H tile per thread
     __shared__ __attribute__((aligned(16))) float G[BF ? 1 : GBM][BF ? 4 : LDG];
     __shared__ __attribute__((aligned(16))) __bf16 Gb[2][BF ? GBM : 1][BF ? LDGB : 8];      // BF: [hi, lo][trial][k]
     __shared__ __attribute__((aligned(16))) float Cy[GBM][LDC];
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
     bf16x8 wh[BF ? TPW : 1][NCB], wl[BF ? TPW : 1][NCB];   // BF: WT[j0 + n][32c + 8kq + j] split hi / lo
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-        const int j = (wave + 4 * tt) * 16 + n;
+        const int j = (wave + NW * tt) * 16 + n;
         if constexpr (BF) {
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
@@ -669,14 +679,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
         }
     }
     if constexpr (BF) {
-        for (int i = tid; i < 2 * GBM * LDGB; i += 256) (&Gb[0][0][0])[i] = (__bf16)0.f;
+        for (int i = tid; i < 2 * GBM * LDGB; i += NTHR) (&Gb[0][0][0])[i] = (__bf16)0.f;
     } else {
-        for (int i = tid; i < GBM * LDG; i += 256) (&G[0][0])[i] = 0.f;
+        for (int i = tid; i < GBM * LDG; i += NTHR) (&G[0][0])[i] = 0.f;
     }
-    for (int i = tid; i < GBM * LDC; i += 256) (&Cy[0][0])[i] = 0.f;
+    for (int i = tid; i < GBM * LDC; i += NTHR) (&Cy[0][0])[i] = 0.f;
     __syncthreads();
     if (p.dhn) {
-        for (int i = tid; i < GBM * H; i += 256) {
+        for (int i = tid; i < GBM * H; i += NTHR) {
             const int r = i / H, k = i % H, b = b0 + r;
             if (b < B) Cy[r][k] = p.dhn[((long long)dir * B + b) * H + k];
         }
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
         const int slot_prev_ = (dir == 0) ? t_ : t_ + 2;
 #pragma unroll
         for (int e = 0; e < GPT; ++e) {
-            const int idx = tid + 256 * e;
+            const int idx = tid + NTHR * e;
             const int r = idx / H4, j = (idx % H4) * 4;
             int b = b0 + r;
             b = b < B ? b : B - 1;
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
         bool pend_live[GPT];
 #pragma unroll
         for (int e = 0; e < GPT; ++e) {
-            const int idx = tid + 256 * e;
+            const int idx = tid + NTHR * e;
             const int r = idx / H4, j = (idx % H4) * 4, b = b0 + r;
             float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, danr = dar, keep = dar, dan4 = dar;
             pend_live[e] = b < B;
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
         }
         auto issue_store = [&](int k) {        // k compile-time at every call site
             const int e = k / 4, what = k % 4;
-            const int idx = tid + 256 * e;
+            const int idx = tid + NTHR * e;
             const int r = idx / H4, j = (idx % H4) * 4, b = b0 + r;
             if (pend_live[e]) {
                 if (what < 3) *reinterpret_cast<float4*>(p.dgi + (((long long)dir * T + t) * B + b) * 3 * H + what * H + j) = pend[k];
@@ -783,7 +793,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
         f32x4 acc[TPW];
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
-            const float4 c4 = *reinterpret_cast<const float4*>(&Cy[n][(wave + 4 * tt) * 16 + 4 * kq]);
+            const float4 c4 = *reinterpret_cast<const float4*>(&Cy[n][(wave + NW * tt) * 16 + 4 * kq]);
             acc[tt] = (f32x4){c4.x, c4.y, c4.z, c4.w};
         }
         if constexpr (BF) {
@@ -830,12 +840,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_resident_kernel(GruBwdParams p
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             const float4 o = live ? make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&Cy[n][(wave + 4 * tt) * 16 + 4 * kq]) = o;
+            *reinterpret_cast<float4*>(&Cy[n][(wave + NW * tt) * 16 + 4 * kq]) = o;
         }
         __syncthreads();
     }
     if (p.dh0) {
-        for (int i = tid; i < GBM * H; i += 256) {
+        for (int i = tid; i < GBM * H; i += NTHR) {
             const int r = i / H, k = i % H, b = b0 + r;
             if (b < B) p.dh0[((long long)dir * B + b) * H + k] = Cy[r][k];
         }
@@ -1156,7 +1166,7 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     dim3 grid(cdiv(B, GBM), ndir);
     if (vec && (H == 128 || H == 64)) {
         const bool bf = xps_internal_gemm_mode() == 1;
-        if (H == 128 && bf) hipLaunchKernelGGL((gru_fwd_resident_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (H == 128 && bf) hipLaunchKernelGGL((gru_fwd_resident_kernel<128, true, GRU_BF_WAVES>), grid, dim3(GRU_BF_WAVES * 64), 0, (hipStream_t)stream, p);
         else if (H == 128) hipLaunchKernelGGL((gru_fwd_resident_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else if (bf) hipLaunchKernelGGL((gru_fwd_resident_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((gru_fwd_resident_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -1242,7 +1252,7 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
     dim3 grid(cdiv(B, GBM), ndir);
     if (vec && (H == 128 || H == 64)) {
         const bool bf = xps_internal_gemm_mode() == 1;
-        if (H == 128 && bf) hipLaunchKernelGGL((gru_bwd_resident_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (H == 128 && bf) hipLaunchKernelGGL((gru_bwd_resident_kernel<128, true, GRU_BF_WAVES>), grid, dim3(GRU_BF_WAVES * 64), 0, (hipStream_t)stream, p);
         else if (H == 128) hipLaunchKernelGGL((gru_bwd_resident_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else if (bf) hipLaunchKernelGGL((gru_bwd_resident_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((gru_bwd_resident_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
