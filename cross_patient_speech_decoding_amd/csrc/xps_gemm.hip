@@ -271,11 +271,29 @@ __device__ inline float slab_sum(const float* __restrict__ p, long long stride, 
     return s;
 }
 
+// 16-byte version of slab_sum: four consecutive slab elements per lane
+__device__ inline f32x4 slab_sum4(const float* __restrict__ p, long long stride, int splits, int w) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int z = w;
+    for (; z + 28 < splits; z += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (long long)(z + 4 * u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; z += 4) s += *reinterpret_cast<const f32x4*>(p + (long long)z * stride);
+    return s;
+}
+
+// One block = 64 lanes x 4 consecutive slab elements x 4 split lanes (one wave each); every size in the slab layout is a
+// multiple of 4 floats, so a lane's four elements belong to one tile (same q, lane: accumulator registers 4q .. 4q + 3) or
+// to the column-sum tail of one problem.
 __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const float* __restrict__ ws) {
-    __shared__ float part[4][RED_OUT];
+    __shared__ f32x4 part[4][RED_OUT];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * RED_OUT + l;
-    bool live = idx < g.total_out;
+    const long long idx = ((long long)blockIdx.x * RED_OUT + l) * 4;
+    const bool live = idx < g.total_out;
     int pi = 0;
     long long base = 0;
     if (live) {
@@ -290,29 +308,31 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
     const long long tile_floats = (long long)((P.M + BM - 1) / BM) * P.tiles_n * TN_TILE;
     const long long split_stride = tn_split_stride(tile_floats / TN_TILE, P.M, P.colsum != nullptr);
     const long long e = idx - base;                       // [0, tile_floats): products in slab order, then M column sums
-    float* dst = nullptr;
-    bool is_cs = false;
-    if (live) {
-        if (e < tile_floats) {
-            const int tile = (int)(e / TN_TILE);
-            int r, c;
-            slab_decode((int)(e % TN_TILE), r, c);
-            const int row = (tile / P.tiles_n) * BM + r, col = (tile % P.tiles_n) * BN + c;
-            live = row < P.M && col < P.N;                // padding of edge tiles
-            if (live) dst = P.C + P.rc.off(row) + col;
-        } else {
-            is_cs = true;
-            live = e - tile_floats < P.M;                 // alignment padding behind the column sums
-            if (live) dst = P.colsum + (e - tile_floats);
-        }
-    }
-    part[w][l] = live ? slab_sum(ws + P.slab_off + e, split_stride, P.splits, w) : 0.f;
+    part[w][l] = live ? slab_sum4(ws + P.slab_off + e, split_stride, P.splits, w) : f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (w == 0 && live) {
-        float s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
-        // accumulate bit 0: products AND column sums add to their destinations; bit 1: the column sums only
-        if ((P.accumulate & 1) || ((P.accumulate & 2) && is_cs)) s += *dst;
-        *dst = s;
+        const f32x4 s4 = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float* dst = nullptr;
+            bool is_cs = false;
+            if (e < tile_floats) {
+                const int tile = (int)(e / TN_TILE);
+                int r, cc;
+                slab_decode((int)(e % TN_TILE) + c, r, cc);
+                const int row = (tile / P.tiles_n) * BM + r, col = (tile % P.tiles_n) * BN + cc;
+                if (row < P.M && col < P.N) dst = P.C + P.rc.off(row) + col;      // else: padding of an edge tile
+            } else {
+                is_cs = true;
+                if (e - tile_floats + c < P.M) dst = P.colsum + (e - tile_floats + c);   // else: alignment padding
+            }
+            if (dst) {
+                float s = s4[c];
+                // accumulate bit 0: products AND column sums add to their destinations; bit 1: the column sums only
+                if ((P.accumulate & 1) || ((P.accumulate & 2) && is_cs)) s += *dst;
+                *dst = s;
+            }
+        }
     }
 }
 
@@ -604,7 +624,7 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     else
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, false>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     XPS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT)), dim3(256), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT * 4)), dim3(256), 0, (hipStream_t)stream, g,
                        (const float*)workspace);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
