@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
                 int r, cc;
                 slab_decode((int)(e % TN_TILE) + c, r, cc);
                 const int row = (tile / P.tiles_n) * BM + r, col = (tile % P.tiles_n) * BN + cc;
-                if (row < P.M && col < P.N) dst = P.C + P.rc.off(row) + col;      // else: padding of an edge tile
+                if (row < P.M && col < P.N)                                        // else: padding of an edge tile
+                    dst = P.C + (P.rc.rpg >= P.M ? (long long)row * P.rc.ld : P.rc.off(row)) + col;
             } else {
                 is_cs = true;
                 if (e - tile_floats + c < P.M) dst = P.colsum + (e - tile_floats + c);   // else: alignment padding
