@@ -259,6 +259,26 @@ def test_dropout_kernel_statistics_and_backward():
     assert xf.dropout(x, 0.3, False) is x
 
 
+def test_dropout_decisions_are_a_function_of_seed_and_index():
+    """The backward pass regenerates the mask instead of storing it: the same (seed, index) must give the same decision
+    whether the mask is materialised or fused, through the 16-byte and the 8-byte path (n % 4 != 0)."""
+    from cross_patient_speech_decoding_amd._lib import call
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (4096, 4098):
+        x = torch.randn(n, device='cuda')
+        mask = torch.empty(n, device='cuda')
+        out = torch.empty(n, device='cuda')
+        call('xps_dropout_f32', None, None, mask.data_ptr(), n, 0.4, 777, st)
+        call('xps_dropout_f32', x.data_ptr(), out.data_ptr(), None, n, 0.4, 777, st)
+        torch.cuda.synchronize()
+        assert set(mask.unique().tolist()) <= {0.0, 1.0}
+        np.testing.assert_array_equal(out.cpu().numpy(), (x * mask * np.float32(1.0 / (1.0 - np.float32(0.4)))).cpu().numpy())
+    a = torch.empty(4096, device='cuda'); b = torch.empty(4098, device='cuda')
+    call('xps_dropout_f32', None, None, a.data_ptr(), 4096, 0.4, 777, st)
+    call('xps_dropout_f32', None, None, b.data_ptr(), 4098, 0.4, 777, st)
+    assert torch.equal(a, b[:4096])                      # vector and pair paths agree element for element
+
+
 def test_gru_recurrence_with_h0_and_dh0(gemm_precision):
     torch.set_num_threads(4)
     T, B, H = 1, 9, 24
