@@ -306,11 +306,12 @@ __device__ inline void gemm_accumulate(f32x16 (&acc)[MI][2], float& csum, const 
 // three bf16 MFMAs (3 x 1/16 of the fp32-MFMA time) for a product exact to ~2^-16 relative (the dropped lo*lo term),
 // i.e. 256x tighter than a plain bf16 GEMM and within the 1e-4 parity bar of the model.  The C/D layout of the
 // 32x32 bf16 MFMA equals the fp32 form's, so gemm_store and every epilogue are shared with the fp32 pipeline.
-// LDS image per operand and buffer: hi[128][24] + lo[128][24] shorts: row = x (m or n), 16 k-contiguous bf16 + 16 B
-// pad -> 48-byte rows: the operand reads (ds_read_b128: lane -> row, k half) are bank-conflict free.
+// LDS image per operand and buffer (BfTile).  [x][k] operands: hi[128][24] + lo[128][24] shorts, row = x (m or n),
+// 16 k-contiguous bf16 + 16 B pad -> 48-byte rows: the fragment reads (ds_read_b128: lane -> row, k half) are
+// bank-conflict free.  [k][x] operands are NOT transposed on the way in: rows of k (320 B), fragments gathered with the
+// transposing ds_read_b64_tr_b16 (bf_frag).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int BFROW = 24;                                // shorts per LDS row (BKT = 16 used + 8 pad)
 static_assert(BKT == 16, "the bf16 pipeline maps one k-tile to one 32x32x16 MFMA step");
 constexpr int BFTROW = 160;                              // shorts per row of the [k][x] image: 128 + 32 pad (320 B: the four
