@@ -30,13 +30,19 @@ namespace {
 // C (+)= A B (+ A2 B2) + bias.  MI = 1: 64 x 128 tiles (twice the blocks, for grids that would not fill
 // the chip with 128 x 128 tiles);  A2/B2: an optional second operand pair with the same row maps (the two
 // directions of a bidirectional layer summed in registers instead of a second accumulate pass).
+// 64-row tiles of the bf16 pipeline use 36 KB of LDS per block, so four blocks would fit a CU if the kernel kept to 128
+// registers (-DXPS_BF_MI1_WAVES=4).  Measured: the projections gain 3-6 %, the two-operand input-gradient form loses 15 %
+// to spills, the step is unchanged — three blocks per CU stay the default.
+#ifndef XPS_BF_MI1_WAVES
+#define XPS_BF_MI1_WAVES XPS_GEMM_WAVES
+#endif
 template <bool AK, bool BK, int MI, bool EDGE = false, bool BF = false>
-__global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_f32_kernel(
+__global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_WAVES) void gemm_f32_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
     const float* __restrict__ A2, const float* __restrict__ B2, int K2,
     float* __restrict__ C, RowMap rc, const float* __restrict__ bias,
     int M, int N, int K, int kchunk, long long slab_stride, int accumulate, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
+    __shared__ __attribute__((aligned(16))) TileMem<BF, MI> mem;
     // 1-D grid, logical order (k-split, m-tile, n-tile): the n-tiles of an A panel run on one XCD
     const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + 64 * MI - 1) / (64 * MI));
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -137,10 +143,10 @@ struct NtMulti {
     float* C[4];
 };
 template <int MI, bool EDGE = false, bool BF = false>
-__global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
+__global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int nprob,
     int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
+    __shared__ __attribute__((aligned(16))) TileMem<BF, MI> mem;
     // logical order (m-tile, problem, n-tile): all blocks that read one A panel are neighbours on one XCD
     const int tiles_n = (N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);

@@ -314,22 +314,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BFROW = 24;                                // shorts per LDS row (BKT = 16 used + 8 pad)
 static_assert(BKT == 16, "the bf16 pipeline maps one k-tile to one 32x32x16 MFMA step");
-constexpr int BFTROW = 160;                              // shorts per row of the [k][x] image: 128 + 32 pad (320 B: the four
-                                                         // k rows of a transposed read start 16 banks apart)
+// [k][x] image: W + 32 shorts per k row (W = 128: 320 B, W = 64: 192 B): the four k rows of a transposed read start 16 banks apart
+template <int W>                                         // W = rows (x extent) of the staged operand tile: 64 or 128
 struct BfTile {
     union {
         struct {                                         // [x][k] operands: row = x, 16 k-contiguous bf16 (+ pad)
-            __bf16 hi[128][BFROW];
-            __bf16 lo[128][BFROW];
+            __bf16 hi[W][BFROW];
+            __bf16 lo[W][BFROW];
         };
         struct {                                         // [k][x] operands: stored as they are loaded, row = k
-            __bf16 thi[BKT][BFTROW];
-            __bf16 tlo[BKT][BFTROW];
+            __bf16 thi[BKT][W + 32];
+            __bf16 tlo[BKT][W + 32];
         };
     };
 };
-struct BfStage {                                         // what a kernel declares in LDS: 2 buffers x (A, B)
-    BfTile a[2], b[2];
+template <int MI>                                        // what a kernel declares in LDS: 2 buffers x (A: 64 MI rows, B: 128)
+struct BfStage {
+    BfTile<64 * MI> a[2];
+    BfTile<128> b[2];
 };
 
 __device__ inline void bf_split(float x, __bf16& hi, __bf16& lo) {
@@ -338,7 +340,7 @@ __device__ inline void bf_split(float x, __bf16& hi, __bf16& lo) {
 }
 
 template <bool KCONTIG, int W>
-__device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], BfTile& S, int tid) {
+__device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], BfTile<W>& S, int tid) {
     using L = TileLoader<KCONTIG, W, true>;
     if (KCONTIG) {
         const int k4 = (tid % KL) * 4;
@@ -371,8 +373,8 @@ __device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::N
 // [x][k] image: one ds_read_b128.  [k][x] image: two ds_read_b64_tr_b16 — per 16-lane group the hardware reads a block of
 // 4 k rows x 16 x columns and hands lane i column i (4 consecutive k of one x); lane 4q + p supplies the address of
 // row q, columns 4p .. 4p + 3.  Needs EXEC = all ones (no divergence around the k loop).
-template <bool KCONTIG>
-__device__ inline void bf_frag(const BfTile& S, int x0, int lane, bf16x8& fh, bf16x8& fl) {
+template <bool KCONTIG, int W>
+__device__ inline void bf_frag(const BfTile<W>& S, int x0, int lane, bf16x8& fh, bf16x8& fl) {
     if constexpr (KCONTIG) {
         fh = *reinterpret_cast<const bf16x8*>(&S.hi[x0 + (lane & 31)][(lane >> 5) * 8]);
         fl = *reinterpret_cast<const bf16x8*>(&S.lo[x0 + (lane & 31)][(lane >> 5) * 8]);
@@ -405,7 +407,7 @@ template <bool AK, bool BK, int MI, int MODE>
 __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const bool want_csum,
                                         const TileLoader<AK, 64 * MI, true>& la, const TileLoader<BK, 128, true>& lb,
                                         const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
-                                        int M, int N, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage& S) {
+                                        int M, int N, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage<MI>& S) {
     constexpr int WM = 64 * MI;
     using LA = TileLoader<AK, WM, true>;
     using LB = TileLoader<BK, 128, true>;
@@ -436,9 +438,9 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
         {
             bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) bf_frag<AK>(S.a[buf], wm + i * 32, lane, ah[i], al[i]);
+            for (int i = 0; i < MI; ++i) bf_frag<AK, 64 * MI>(S.a[buf], wm + i * 32, lane, ah[i], al[i]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf_frag<BK>(S.b[buf], wn + j * 32, lane, bh[j], bl[j]);
+            for (int j = 0; j < 2; ++j) bf_frag<BK, 128>(S.b[buf], wn + j * 32, lane, bh[j], bl[j]);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -464,7 +466,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
 template <bool AK, bool BK, int MI, bool EDGE = false>
 __device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], f32x4& csum, const bool want_csum,
                                           const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
-                                          int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage& S) {
+                                          int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage<MI>& S) {
     TileLoader<AK, 64 * MI, true> la;
     TileLoader<BK, 128, true> lb;
     la.init(A, ra, m0, M, K, threadIdx.x, vecA);
@@ -486,19 +488,19 @@ __device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], f32x4& csum, con
 }
 
 // the staging memory of a tile kernel in either precision mode (BF = false: the fp32 k-major tiles)
-template <bool BF> struct TileMem;
-template <> struct TileMem<false> {
+template <bool BF, int MI = 2> struct TileMem;
+template <int MI> struct TileMem<false, MI> {
     float As[2][BKT][LDT];
     float Bs[2][BKT][LDT];
 };
-template <> struct TileMem<true> {
-    BfStage st;
+template <int MI> struct TileMem<true, MI> {
+    BfStage<MI> st;
 };
 template <bool AK, bool BK, int MI, bool EDGE, bool BF>
 __device__ inline void gemm_accumulate_any(f32x16 (&acc)[MI][2], float& csum, f32x4& csum4, const bool want_csum,
                                            const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                            int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
-                                           TileMem<BF>& mem) {
+                                           TileMem<BF, MI>& mem) {
     // csum (fp32 pipeline: one column, half the k rows per thread) / csum4 (bf16 pipeline: see bf_colsum)
     if constexpr (BF) gemm_accumulate_bf<AK, BK, MI, EDGE>(acc, csum4, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.st);
     else gemm_accumulate<AK, BK, MI, EDGE>(acc, csum, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.As, mem.Bs);

@@ -1026,7 +1026,7 @@ struct GruStepBwd {
 template <bool BF>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruStepBwd p) {
     using namespace xps_tile;
-    __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
+    __shared__ __attribute__((aligned(16))) TileMem<BF, 1> mem;
     const int dir = blockIdx.z, H = p.H, B = p.B, T = p.T;
     const int ldy = p.ndir * H;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 128;
