@@ -16,8 +16,19 @@ class RowMap(C.Structure):
     _fields_ = [('gs', C.c_int64), ('ld', C.c_int64), ('rpg', C.c_int32), ('pad_', C.c_int32)]
 
 
+_rowmaps = {}
+
+
 def rowmap(ld, rpg=1 << 30, gs=0):
-    return RowMap(int(gs), int(ld), int(rpg), 0)
+    """xps_rowmap descriptor.  Instances are cached and shared (the library only reads them; embedding one in an
+    xps_tn_problem copies it): building a ctypes struct costs ~2 us and a training step needs ~40 of them."""
+    key = (ld, rpg, gs)
+    r = _rowmaps.get(key)
+    if r is None:
+        r = RowMap(int(gs), int(ld), int(rpg), 0)
+        if len(_rowmaps) < 4096:
+            _rowmaps[key] = r
+    return r
 
 
 class TnProblem(C.Structure):

@@ -107,6 +107,9 @@ def tn_problem(A, B, out, M, N, K, ra=None, rb=None, rc=None, colsum_out=None, a
                      rc or rowmap(N), M, N, K, int(bool(accumulate)) | (2 if accumulate_colsum else 0))
 
 
+_tn_ws_bytes = {}
+
+
 def gemm_tn_grouped(problems, device, stream=None):
     """All problems in ONE split-K launch + ONE reduce launch (deterministic).  stream: raw HIP stream handle to launch
     on (default: torch's current stream); returns the workspace tensors (the caller of a foreign-stream launch keeps them
@@ -116,7 +119,12 @@ def gemm_tn_grouped(problems, device, stream=None):
     for i in range(0, len(problems), 12):
         chunk = problems[i:i + 12]
         arr = (TnProblem * len(chunk))(*chunk)
-        nbytes = lib().xps_gemm_tn_grouped_f32_workspace(arr, len(chunk))
+        key = tuple((q.M, q.N, q.K, bool(q.colsum_a)) for q in chunk)        # the slab layout depends on the shapes only
+        nbytes = _tn_ws_bytes.get(key)
+        if nbytes is None:
+            nbytes = lib().xps_gemm_tn_grouped_f32_workspace(arr, len(chunk))
+            if len(_tn_ws_bytes) < 1024:
+                _tn_ws_bytes[key] = nbytes
         ws = _ws(nbytes, device)
         call('xps_gemm_tn_grouped_f32', arr, len(chunk), _ptr(ws), nbytes, st)
         keep.append(ws)
