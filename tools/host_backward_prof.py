@@ -1,0 +1,40 @@
+"""cProfile inside the autograd thread: what the Python backward functions spend their host time on."""
+import os, sys, cProfile, pstats, io
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from cross_patient_speech_decoding_amd.nn_models import functional as XF
+from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+pr = cProfile.Profile()
+def prof(fn):
+    def w(*a, **k):
+        pr.enable()
+        try:
+            return fn(*a, **k)
+        finally:
+            pr.disable()
+    return staticmethod(w)
+for cls in [XF.GRULayerFn, XF.TemporalConvFn, XF.DecoderFn, XF.LinearFn, XF.CrossEntropyFn, XF.DropoutFn]:
+    cls.backward = prof(cls.backward)
+c = bench.CFG
+torch.manual_seed(1234)
+model = bench.build_model(c).cuda()
+opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5)
+X, y = bench.make_data(0, c); X, y = X[:256].cuda(), y[:256].cuda()
+model.train()
+one = torch.ones((), device='cuda')
+def step():
+    opt.zero_grad()
+    logits = model(X, y, teacher_forcing_ratio=0.5)
+    loss = model.criterion(logits.view(-1, 9), y.view(-1))
+    loss.backward(one)
+    opt.step()
+for _ in range(20): step()
+torch.cuda.synchronize()
+pr.clear()
+n = 100
+for _ in range(n): step()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(22)
+print(s.getvalue()[:6000])
