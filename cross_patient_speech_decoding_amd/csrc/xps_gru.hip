@@ -911,6 +911,24 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
         const int li = lane & 31, lk = lane >> 5;
         const int nkt = (H + BKT - 1) / BKT;
         f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
+        // the gate epilogue's inputs (input projections of this step, previous state) do not depend on the product: they
+        // are requested NOW and arrive under the k loop.  Loaded row by row inside the epilogue they formed a chain of
+        // sixteen dependent global round trips (the stores of row r may alias the loads of row r + 1 for the compiler).
+        float e_r[16], e_z[16], e_n[16], e_h[16];
+        {
+            const int je = j0 + li;
+            const float* gie = p.gi + ((long long)dir * T + t) * B * 3 * H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const bool ok = b < B && je < H;
+                const float* gp = gie + (long long)(ok ? b : 0) * 3 * H + (ok ? je : 0);
+                e_r[r] = ok ? gp[0] : 0.f;
+                e_z[r] = ok ? gp[H] : 0.f;
+                e_n[r] = ok ? gp[2 * H] : 0.f;
+                e_h[r] = ok ? hprev[(long long)b * ldy + je] : 0.f;
+            }
+        }
         la.load(ra0, hprev, ra, m0, B, 0, H, tid, p.vecA);
         lb.load(rb0, Wb, rb, 0, 96, 0, H, tid, p.vecB);
         if (nkt > 1) {
@@ -968,17 +986,15 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
         if (j < H) {
             const float* bh = p.b_hh[dir];
             const float b_r = bh[j], b_z = bh[H + j], b_n = bh[2 * H + j];
-            const float* gi = p.gi + ((long long)dir * T + t) * B * 3 * H;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int b = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (b < B) {
-                    const float* gp = gi + (long long)b * 3 * H;
-                    const float rg = sigmoidf_acc(gp[j] + acc[0][r] + b_r);
-                    const float zg = sigmoidf_acc(gp[H + j] + acc[1][r] + b_z);
+                    const float rg = sigmoidf_acc(e_r[r] + acc[0][r] + b_r);
+                    const float zg = sigmoidf_acc(e_z[r] + acc[1][r] + b_z);
                     const float q = acc[2][r] + b_n;
-                    const float ng = tanhf(gp[2 * H + j] + rg * q);
-                    const float hp = hprev[(long long)b * ldy + j];
+                    const float ng = tanhf(e_n[r] + rg * q);
+                    const float hp = e_h[r];
                     p.y_ext[((long long)(t + 1) * B + b) * ldy + dir * H + j] = ng + zg * (hp - ng);
                     if (p.saved) {
                         float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H;
@@ -1052,32 +1068,55 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruStepBwd p) {
     const int li = lane & 31, lk = lane >> 5;
     const int t = (dir == 0) ? p.s : T - 1 - p.s;
     const int slot_prev = (dir == 0) ? t : t + 2;
+    // inputs and outputs of the gate-gradient epilogue never overlap; without the promise the stores of one row order the
+    // loads of the next and the 16 rows become 16 dependent global round trips.  All inputs of a 32-unit column block are
+    // requested first (7 loads x 16 rows), then the rows are computed and stored.
+    const float* __restrict__ in_dhn = p.dhn;
+    const float* __restrict__ in_keep = p.keep_in;
+    const float* __restrict__ in_dy = p.dy;
+    const float* __restrict__ in_saved = p.saved;
+    const float* __restrict__ in_y = p.y_ext;
+    float* __restrict__ out_dgi = p.dgi;
+    float* __restrict__ out_dghn = p.dghn;
+    float* __restrict__ out_keep = p.keep_out;
+    float* __restrict__ out_dh0 = p.dh0;
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
         const int j = n0 + wn + jn * 32 + li;
         if (j >= H) continue;
+        float v_base[16], v_dy[16], v_r[16], v_z[16], v_n[16], v_q[16], v_hp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const bool ok = b < B;
+            const int bc = ok ? b : 0;
+            const long long ob = ((long long)dir * B + bc) * H + j;
+            v_base[r] = p.first ? (in_dhn ? in_dhn[ob] : 0.f) : in_keep[ob];
+            if (!p.final) {
+                v_dy[r] = in_dy ? in_dy[((long long)t * B + bc) * ldy + dir * H + j] : 0.f;
+                const float* sv = in_saved + (((long long)dir * T + t) * B + bc) * 4 * H;
+                v_r[r] = sv[j]; v_z[r] = sv[H + j]; v_n[r] = sv[2 * H + j]; v_q[r] = sv[3 * H + j];
+                v_hp[r] = in_y[((long long)slot_prev * B + bc) * ldy + dir * H + j];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int b = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (b >= B) continue;
             const long long ob = ((long long)dir * B + b) * H + j;
-            float dh = acc[0][jn][r];
-            if (p.first) dh = p.dhn ? p.dhn[ob] : 0.f;
-            else dh += p.keep_in[ob];
-            if (p.final) { p.dh0[ob] = dh; continue; }
-            if (p.dy) dh += p.dy[((long long)t * B + b) * ldy + dir * H + j];
-            const float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H;
-            const float rg = sv[j], zg = sv[H + j], ng = sv[2 * H + j], q = sv[3 * H + j];
-            const float hp = p.y_ext[((long long)slot_prev * B + b) * ldy + dir * H + j];
+            float dh = p.first ? v_base[r] : acc[0][jn][r] + v_base[r];
+            if (p.final) { out_dh0[ob] = dh; continue; }
+            dh += v_dy[r];
+            const float rg = v_r[r], zg = v_z[r], ng = v_n[r], q = v_q[r], hp = v_hp[r];
             const float dn = dh * (1.f - zg);
             const float dz = dh * (hp - ng);
             const float dan = dn * (1.f - ng * ng);
             const long long o = (((long long)dir * T + t) * B + b) * 3 * H;
-            p.dgi[o + j] = dan * q * rg * (1.f - rg);
-            p.dgi[o + H + j] = dz * zg * (1.f - zg);
-            p.dgi[o + 2 * H + j] = dan;
-            p.dghn[(((long long)dir * T + t) * B + b) * H + j] = dan * rg;
-            p.keep_out[ob] = dh * zg;
+            out_dgi[o + j] = dan * q * rg * (1.f - rg);
+            out_dgi[o + H + j] = dz * zg * (1.f - zg);
+            out_dgi[o + 2 * H + j] = dan;
+            out_dghn[(((long long)dir * T + t) * B + b) * H + j] = dan * rg;
+            out_keep[ob] = dh * zg;
         }
     }
 }
