@@ -24,6 +24,17 @@ using xps_tile::bf16x4;
 using xps_tile::bf16x8;
 using xps_tile::bf_split;
 
+// cluster-persistent recurrence for 128 < H <= 512 (xps_gru_cluster.hip)
+bool xps_internal_gru_cluster_usable(int B, int H, int ndir);
+size_t xps_internal_gru_cluster_fwd_workspace(int B, int H, int ndir);
+size_t xps_internal_gru_cluster_bwd_workspace(int B, int H, int ndir);
+size_t xps_internal_gru_cluster_status_offset(int B, int H, int ndir);
+int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh, const float* h0,
+                                 float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st);
+int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                                 const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                                 int T, int B, int H, int ndir, void* workspace, hipStream_t st);
+
 namespace {
 
 constexpr int GBM = 16;   // trials per workgroup
@@ -1163,12 +1174,34 @@ inline bool use_step_path() {
 
 }  // namespace
 
+static bool cluster_shape_ok(int T, int B, int H, int ndir) {
+    return xps_internal_gru_cluster_usable(B, H, ndir) && (long long)(T + 2) * B * ndir * H * 4 < (1ll << 32);
+}
+
+extern "C" size_t xps_gru_seq_fwd_f32_workspace(int T, int B, int H, int ndir) {
+    if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return 16;
+    return cluster_shape_ok(T, B, H, ndir) ? xps_internal_gru_cluster_fwd_workspace(B, H, ndir) : 16;
+}
+
+extern "C" long long xps_gru_seq_status_offset(int T, int B, int H, int ndir) {
+    if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return -1;
+    return cluster_shape_ok(T, B, H, ndir) ? (long long)xps_internal_gru_cluster_status_offset(B, H, ndir) : -1;
+}
+
 extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                    const float* h0, float* y_ext, float* saved,
-                                   int T, int B, int H, int ndir, void* stream) {
+                                   int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream) {
     XPS_CHECK_ARG(gi && w_hh && b_hh && y_ext, "null argument");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
+    if (cluster_shape_ok(T, B, H, ndir)) {
+        XPS_CHECK_ARG(w_hh[0] && b_hh[0] && (ndir == 1 || (w_hh[1] && b_hh[1])), "null weight pointer");
+        if (!workspace || workspace_bytes < xps_gru_seq_fwd_f32_workspace(T, B, H, ndir)) {
+            xps_set_error("xps_gru_seq_fwd_f32: workspace too small");
+            return XPS_E_WORKSPACE;
+        }
+        return xps_internal_gru_cluster_fwd(gi, w_hh, b_hh, h0, y_ext, saved, T, B, H, ndir, workspace, (hipStream_t)stream);
+    }
     GruFwdParams p;
     p.gi = gi; p.h0 = h0; p.y_ext = y_ext; p.saved = saved;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;
@@ -1228,6 +1261,7 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
 extern "C" size_t xps_gru_seq_bwd_f32_workspace(int T, int B, int H, int ndir) {
     (void)T;
     if (B <= 0 || H <= 0 || ndir <= 0) return 16;
+    if (T > 0 && (ndir == 1 || ndir == 2) && cluster_shape_ok(T, B, H, ndir)) return xps_internal_gru_cluster_bwd_workspace(B, H, ndir);
     return (size_t)2 * ndir * B * H * sizeof(float) + 16;       // ping-pong running gradient of the per-step path
 }
 
@@ -1238,6 +1272,14 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
     XPS_CHECK_ARG(dy || dhn, "at least one of dy / dhn must be given");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
+    if (cluster_shape_ok(T, B, H, ndir)) {
+        XPS_CHECK_ARG(w_hh_t[0] && (ndir == 1 || w_hh_t[1]), "null weight pointer");
+        if (!workspace || workspace_bytes < xps_gru_seq_bwd_f32_workspace(T, B, H, ndir)) {
+            xps_set_error("xps_gru_seq_bwd_f32: workspace too small");
+            return XPS_E_WORKSPACE;
+        }
+        return xps_internal_gru_cluster_bwd(dy, dhn, y_ext, saved, w_hh_t, dgi, dghn, dh0, T, B, H, ndir, workspace, (hipStream_t)stream);
+    }
     GruBwdParams p;
     p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;

@@ -1,0 +1,886 @@
+// Cluster-persistent GRU recurrence for 128 < H <= 512 on gfx950 (the north-star shape: H = 512 / 500,
+// nn_models/models.py:661-699).  W_hh (3H x H, 3 MB at H = 512) does not fit one CU, so a CLUSTER of
+// CS workgroups (one per CU) shares it: member m keeps the rows of its U hidden units of all three gates
+// resident in the VGPRs of its four waves for the WHOLE sequence (192 registers per lane: fp32, or the
+// bf16 hi/lo split made once per launch) and the cluster works on Mc trials.  Per step a member needs the
+// complete previous state h_{t-1} of its trials (forward) or the complete gate gradients (backward): the
+// members exchange them through a small ping-pong buffer in global memory (L2), inside the launch.
+//
+//   forward : H in (256, 512]: U = 32, CS = H/32 (16), wave (ut, kh) owns 16 units x 3 gates x 256 k
+//             H in (128, 256]: U = 64, CS = H/64 (4),  wave ut owns 16 units x 3 gates x 256 k
+//   grid    : ndir x nblk clusters, nblk = trial blocks per direction, <= one workgroup per CU
+//   round   : 32 trials (two 16-trial MFMA column tiles); per round a wave issues 144 MFMAs
+//             (v_mfma_f32_16x16x32_bf16 on split operands: lo*hi + hi*lo + hi*hi; fp32 mode: 16x16x4 f32),
+//             the two k-halves of a unit tile swap their partial sums through LDS and each runs the gate
+//             math of one trial tile.  Lane (n, kq) owns trial n and FOUR CONSECUTIVE units: every global
+//             access is a 16-byte vector.
+//
+// Hand-off protocol (MI355X_MICROARCH.md "Valid forms", first table row; cdna_hip_programming.md G16 R1):
+// every exchanged byte is stored write-through (sc1) and loaded with sc1 loads to registers; a member
+// publishes round r of step s by ONE lane's sc1 flag store after a workgroup barrier that every storing
+// wave reaches only once loads it issued AFTER those stores have returned (vmcnt retires in order, so the
+// stores have completed); consumers poll the CS flags of the round with one sc1 load by one wave, and the
+// other waves load behind a barrier that wave joins afterwards.  Publication lags one round and polls run
+// two rounds ahead, so in steady state nobody waits; the dependency chain needs NR >= 4 rounds per
+// cluster (checked on the host).  Every spin is bounded (status word, checked by the caller).
+// XPS_GRU_CLUSTER=steps runs the SAME kernels one step per launch (no in-kernel hand-off at all).
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "xps_common.h"
+#include "xps_gemm_tile.h"
+using xps_tile::bf16x4;
+using xps_tile::bf16x8;
+using xps_tile::bf_split;
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int AUX_SC1 = 16;                 // cache-policy bits of the raw buffer builtins on gfx94x/gfx950: bit 4 = sc1
+constexpr unsigned RSRC_FLAGS = 0x00020000; // buffer descriptor dword 3 for gfx9 raw buffers
+
+template <int KSPLIT, bool BF, int KSEG>
+struct ClCfg {
+    static constexpr int KP = 256 * KSPLIT;                  // padded hidden size (k extent of one gate segment)
+    static constexpr int NUT = 4 / KSPLIT;                   // 16-unit tiles per workgroup
+    static constexpr int U = 16 * NUT;                       // hidden units per workgroup
+    static constexpr int ROWB = BF ? KP * 2 : KP * 4;        // bytes of one LDS row: one trial (and one plane: hi or lo)
+    static constexpr int RS = BF ? ROWB + 16 : ROWB + 32;    // row stride: trials 8 dwords (mod 64) apart -> conflict-free b128 reads
+    static constexpr int NROW = BF ? 64 : 32;
+    static constexpr int TILE_BYTES = NROW * RS;             // LDS image of one round's operand (32 trials x KP)
+    static constexpr int CHUNK_BYTES = 32 * KP * 4;          // the same in global memory: [trial32][plane][KP] bf16 or [trial32][KP] f32
+    static constexpr int PIECES = CHUNK_BYTES / 16 / 256;    // 16-byte pieces per thread
+    static constexpr int PPR = ROWB / 16;                    // pieces per row
+    static constexpr int XCH_BYTES = KSPLIT == 2 ? 2 * 4 * 3 * 1024 : 0;   // partial-sum swap, double buffered
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES + XCH_BYTES;
+    static constexpr int KSEGS = KSEG;                       // gate segments of the contraction (forward 1, backward 3)
+};
+
+__device__ inline float cl_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ inline float cl_tanh(float x) { return 2.0f * cl_sigmoid(2.0f * x) - 1.0f; }
+
+// one wave polls the CS flags of a round until every member has published `need`; bounded (3 s)
+__device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int lane, unsigned first, unsigned* status) {
+    unsigned v = first;
+    if (__all(v >= need)) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    for (;;) {
+        v = need;
+        if (lane < cs) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= need)) return;
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
+            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+
+struct ClMap { int cluster, member; };
+__device__ inline ClMap cl_map(int CS) {
+    // members of a cluster share blockIdx % 8 (one XCD under round-robin placement) when the grid allows: speed only
+    const int G = gridDim.x, bid = blockIdx.x;
+    ClMap m;
+    if (G % (8 * CS) == 0) {
+        const int xcd = bid & 7, slot = bid >> 3;
+        m.cluster = xcd * (G / 8 / CS) + slot / CS;
+        m.member = slot % CS;
+    } else {
+        m.cluster = bid / CS;
+        m.member = bid % CS;
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+struct ClFwd {
+    const float* gi;
+    const float* w_hh[2];
+    const float* b_hh[2];
+    float* y_ext;
+    float* saved;
+    void* xbuf;            // [2 parity][ndir][Bp] rows of KP elements (bf16 hi plane + lo plane, or f32)
+    unsigned* flags;       // [cluster][NR][16]
+    unsigned* status;
+    unsigned xbuf_bytes;
+    int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
+    int s_begin, s_end, handoff;
+};
+
+template <int KSPLIT, bool BF>
+__global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
+    using Cf = ClCfg<KSPLIT, BF, 1>;
+    constexpr int KP = Cf::KP, RS = Cf::RS, PIECES = Cf::PIECES, PPR = Cf::PPR, TILE = Cf::TILE_BYTES;
+    constexpr int NTE = KSPLIT == 2 ? 1 : 2;          // trial tiles whose gate math this wave runs per round
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xch = smem + 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int ut = wave / KSPLIT, kh = wave % KSPLIT;
+    const ClMap cm = cl_map(p.CS);
+    const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
+    const int T = p.T, B = p.B, H = p.H, NR = p.NR;
+    const int j0 = cm.member * Cf::U + ut * 16;        // first unit of this wave's tile
+    const int ju = j0 + 4 * kq;                        // this lane's four units
+    const bool ulive = ju < H;
+    const int juc = ulive ? ju : 0;
+    const int kbase = kh * 256;
+    const int ldy = p.ndir * H;
+    const int m_base = blk * p.Mc;
+    const float* __restrict__ W = p.w_hh[dir];
+    const float* __restrict__ gi = p.gi + (long long)dir * T * B * 3 * H;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y_ext, 0, (unsigned)((long long)(T + 2) * B * ldy * 4), RSRC_FLAGS);
+    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
+
+    // ---- resident weights: A operand rows = units j0 + n of gate g, k = kbase + ... ----
+    bf16x8 wh[BF ? 3 : 1][BF ? 8 : 1], wl[BF ? 3 : 1][BF ? 8 : 1];
+    float wf[BF ? 1 : 3][BF ? 1 : 16][4];
+    {
+        const int jr = j0 + n;
+        const bool rlive = jr < H;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float* wrow = W + (long long)(g * H + (rlive ? jr : 0)) * H;
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = kbase + 32 * c + 8 * kq;
+                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                    if (rlive && k + 3 < H) v0 = *reinterpret_cast<const f32x4*>(wrow + k);
+                    if (rlive && k + 7 < H) v1 = *reinterpret_cast<const f32x4*>(wrow + k + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        __bf16 a, b;
+                        bf_split(v0[e], a, b); wh[g][c][e] = a; wl[g][c][e] = b;
+                        bf_split(v1[e], a, b); wh[g][c][4 + e] = a; wl[g][c][4 + e] = b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int k = kbase + 16 * c + 4 * kq;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (rlive && k + 3 < H) v = *reinterpret_cast<const f32x4*>(wrow + k);
+                    wf[g][c][0] = v[0]; wf[g][c][1] = v[1]; wf[g][c][2] = v[2]; wf[g][c][3] = v[3];
+                }
+            }
+        }
+    }
+    f32x4 bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bias[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ulive) bias[g] = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + g * H + ju);
+    }
+
+    // ---- operand staging: global (sc1) -> registers -> LDS image of iteration itn ----
+    auto stage_issue = [&](int itn, u32x4 (&st)[PIECES]) {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        const unsigned base = (unsigned)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (unsigned)(KP * 4);
+#pragma unroll
+        for (int e = 0; e < PIECES; ++e)
+            st[e] = __builtin_amdgcn_raw_buffer_load_b128(xr, base + (unsigned)(tid + 256 * e) * 16u, 0, AUX_SC1);
+    };
+    auto stage_commit = [&](int itn, const u32x4 (&st)[PIECES]) {
+        unsigned char* dst = smem + (itn & 1) * TILE;
+#pragma unroll
+        for (int e = 0; e < PIECES; ++e) {
+            const int i = tid + 256 * e;
+            *reinterpret_cast<u32x4*>(dst + (i / PPR) * RS + (i % PPR) * 16) = st[e];
+        }
+    };
+
+    const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
+    {
+        u32x4 st0[PIECES];
+        stage_issue(it_begin, st0);
+        stage_commit(it_begin, st0);
+    }
+    __syncthreads();
+
+    for (int it = it_begin; it < it_end; ++it) {
+        const int s = it / NR, r = it - s * NR;
+        const int t = (dir == 0) ? s : T - 1 - s;
+        const int slot_prev = (dir == 0) ? t : t + 2;
+        // (A) requests: next round's operand, this round's gate inputs, the flags of the round after next
+        u32x4 st[PIECES];
+        const bool has_next = it + 1 < it_end;
+        if (has_next) stage_issue(it + 1, st);
+        const int it2 = it + 2;
+        const int s2 = it2 / NR, r2 = it2 - s2 * NR;
+        const bool do_poll = p.handoff && wave == 0 && it2 < it_end && s2 > p.s_begin;
+        unsigned fl = 0xffffffffu;
+        if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 e_r[NTE], e_z[NTE], e_n[NTE];
+        u32x4 e_h[NTE];
+#pragma unroll
+        for (int te = 0; te < NTE; ++te) {
+            const int tsel = KSPLIT == 2 ? kh : te;
+            const int b = m_base + 32 * r + 16 * tsel + n;
+            const int bc = b < B ? b : B - 1;
+            const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
+            e_r[te] = *reinterpret_cast<const f32x4*>(gp);
+            e_z[te] = *reinterpret_cast<const f32x4*>(gp + H);
+            e_n[te] = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+            // own previous state (fp32), written by this lane one step ago (or by the init kernel)
+            e_h[te] = __builtin_amdgcn_raw_buffer_load_b128(yr, (unsigned)((((long long)slot_prev * B + bc) * ldy + dir * H + juc) * 4), 0, AUX_SC1);
+        }
+
+        // (B) h_{t-1} W_hh^T for two trial tiles: D[row = unit 4kq + i][col = trial n]
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* tb = smem + (it & 1) * TILE;
+        if constexpr (BF) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const unsigned char* rp = tb + ((tt * 16 + n) * 2) * RS + (kbase + 32 * c + 8 * kq) * 2;
+                    bh[tt] = *reinterpret_cast<const bf16x8*>(rp);
+                    bl[tt] = *reinterpret_cast<const bf16x8*>(rp + RS);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g][c], bh[tt], acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g][c], bl[tt], acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g][c], bh[tt], acc[tt][g], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                f32x4 a4[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * RS + (kbase + 16 * c + 4 * kq) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][c][e], a4[tt][e], acc[tt][g], 0, 0, 0);
+            }
+        }
+
+        // (C) swap partial sums with the other k-half, commit the staged operand, one barrier
+        if constexpr (KSPLIT == 2) {
+            unsigned char* xw = xch + (it & 1) * (4 * 3 * 1024) + wave * (3 * 1024) + lane * 16;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(xw + g * 1024) = kh ? acc[0][g] : acc[1][g];
+        }
+        if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)s2, p.CS, lane, fl, p.status);
+        if (has_next) stage_commit(it + 1, st);
+        __syncthreads();
+        // every wave's exchange stores of the previous round were issued before the loads it has just committed: they are complete
+        if (p.handoff && tid == 0 && it > it_begin) {
+            const int itp = it - 1;
+            const int sp = itp / NR, rp = itp - sp * NR;
+            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        // (D) gates + hidden update for this wave's trial tile(s)
+#pragma unroll
+        for (int te = 0; te < NTE; ++te) {
+            const int tsel = KSPLIT == 2 ? kh : te;
+            f32x4 a_r = tsel ? acc[1][0] : acc[0][0], a_z = tsel ? acc[1][1] : acc[0][1], a_n = tsel ? acc[1][2] : acc[0][2];
+            if constexpr (KSPLIT == 2) {
+                const unsigned char* xr_ = xch + (it & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
+                a_r += *reinterpret_cast<const f32x4*>(xr_);
+                a_z += *reinterpret_cast<const f32x4*>(xr_ + 1024);
+                a_n += *reinterpret_cast<const f32x4*>(xr_ + 2048);
+            }
+            const int b = m_base + 32 * r + 16 * tsel + n;
+            const bool live = b < B;
+            const f32x4 hp = __builtin_bit_cast(f32x4, e_h[te]);      // (whole vector: a bit_cast of ONE element reads element 0)
+            f32x4 o, rg, zg, ng, qv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rg[i] = cl_sigmoid(e_r[te][i] + a_r[i] + bias[0][i]);
+                zg[i] = cl_sigmoid(e_z[te][i] + a_z[i] + bias[1][i]);
+                qv[i] = a_n[i] + bias[2][i];
+                ng[i] = cl_tanh(e_n[te][i] + rg[i] * qv[i]);
+                o[i] = (ulive && live) ? ng[i] + zg[i] * (hp[i] - ng[i]) : 0.f;
+            }
+            // exchange first (write-through), so that the next round's operand loads are younger than these stores
+            if (s + 1 < T) {
+                const unsigned row = (unsigned)((((s + 1) & 1) * p.ndir + dir) * p.Bp + b);
+                if constexpr (BF) {
+                    bf16x4 sh, sl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(o[i], a, c); sh[i] = a; sl[i] = c; }
+                    const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, row * (unsigned)(KP * 4) + (unsigned)ju * 4u, 0, AUX_SC1);
+                }
+            }
+            if (live && ulive) {
+                *reinterpret_cast<f32x4*>(p.y_ext + ((long long)(t + 1) * B + b) * ldy + dir * H + ju) = o;
+                if (p.saved) {
+                    float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H + ju;
+                    *reinterpret_cast<f32x4*>(sv) = rg;
+                    *reinterpret_cast<f32x4*>(sv + H) = zg;
+                    *reinterpret_cast<f32x4*>(sv + 2 * H) = ng;
+                    *reinterpret_cast<f32x4*>(sv + 3 * H) = qv;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");        // the exchange stores stay ahead of the next iteration's loads in program order
+    }
+}
+
+// h0 -> slots of y_ext and parity 0 of the exchange buffer (all Bp rows, all KP columns: pads are zero)
+template <bool BF>
+__global__ void gru_cluster_init_kernel(const float* __restrict__ h0, float* __restrict__ y_ext, void* __restrict__ xbuf,
+                                        int T, int B, int H, int ndir, int Bp, int KP) {
+    const long long total = (long long)ndir * Bp * (KP / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (KP / 4)) * 4;
+        const long long rb = i / (KP / 4);
+        const int b = (int)(rb % Bp), dir = (int)(rb / Bp);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const bool in = b < B && k < H;
+        if (in && h0) v = *reinterpret_cast<const f32x4*>(h0 + ((long long)dir * B + b) * H + k);
+        if (in) {
+            const int slot_h0 = (dir == 0) ? 0 : T + 1, slot_other = (dir == 0) ? T + 1 : 0;
+            const int ldy = ndir * H;
+            *reinterpret_cast<f32x4*>(y_ext + ((long long)slot_h0 * B + b) * ldy + dir * H + k) = v;
+            *reinterpret_cast<f32x4*>(y_ext + ((long long)slot_other * B + b) * ldy + dir * H + k) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        unsigned char* row = reinterpret_cast<unsigned char*>(xbuf) + ((long long)dir * Bp + b) * KP * 4;
+        if constexpr (BF) {
+            bf16x4 sh, sl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { __bf16 a, c; bf_split(v[e], a, c); sh[e] = a; sl[e] = c; }
+            *reinterpret_cast<bf16x4*>(row + k * 2) = sh;
+            *reinterpret_cast<bf16x4*>(row + KP * 2 + k * 2) = sl;
+        } else {
+            *reinterpret_cast<f32x4*>(row + k * 4) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward (BPTT): dh_{t-1} = z * dh_t + [dar | daz | dan*r] W_hh.  Member m owns U output units (rows of
+// W_hh^T: 16 units x 3 x 256 k per wave) and the gate gradients of the same units; the contraction runs
+// over all 3H gate-gradient columns, exchanged per step as three gate segments of KP columns.
+// Processing step ps = 0 .. T-1 handles s = T-1-ps (t = s forward, T-1-s reverse); ps = T is the dh0 pass.
+// ------------------------------------------------------------------------------------------------------
+struct ClBwd {
+    const float* dy;
+    const float* dhn;
+    const float* y_ext;
+    const float* saved;
+    const float* w_hh_t[2];     // (H x 3H)
+    float* dgi;
+    float* dghn;
+    float* dh0;
+    float* keep;                // [ndir][B][H]  z * dh of the step processed before
+    void* xbuf;                 // [2 parity][ndir][Bp/32][3 gates][32 trials] rows of KP elements
+    unsigned* flags;
+    unsigned* status;
+    unsigned xbuf_bytes;
+    int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
+    int ps_begin, ps_end, ps_total, handoff;
+};
+
+template <int KSPLIT, bool BF>
+__global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
+    using Cf = ClCfg<KSPLIT, BF, 3>;
+    constexpr int KP = Cf::KP, RS = Cf::RS, PIECES = Cf::PIECES, PPR = Cf::PPR, TILE = Cf::TILE_BYTES;
+    constexpr int NTE = KSPLIT == 2 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xch = smem + 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int ut = wave / KSPLIT, kh = wave % KSPLIT;
+    const ClMap cm = cl_map(p.CS);
+    const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
+    const int T = p.T, B = p.B, H = p.H, NR = p.NR;
+    const int j0 = cm.member * Cf::U + ut * 16;
+    const int ju = j0 + 4 * kq;
+    const bool ulive = ju < H;
+    const int juc = ulive ? ju : 0;
+    const int kbase = kh * 256;
+    const int ldy = p.ndir * H;
+    const int m_base = blk * p.Mc;
+    const int NQ = 3 * NR;                              // sub-iterations (round, gate segment) per processing step
+    const float* __restrict__ WT = p.w_hh_t[dir];
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
+    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
+
+    // ---- resident weights: A rows = units j0 + n, k = gate segment g, kbase + ... ----
+    bf16x8 wh[BF ? 3 : 1][BF ? 8 : 1], wl[BF ? 3 : 1][BF ? 8 : 1];
+    float wf[BF ? 1 : 3][BF ? 1 : 16][4];
+    {
+        const int jr = j0 + n;
+        const bool rlive = jr < H;
+        const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = kbase + 32 * c + 8 * kq;
+                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                    if (rlive && k + 3 < H) v0 = *reinterpret_cast<const f32x4*>(wrow + g * H + k);
+                    if (rlive && k + 7 < H) v1 = *reinterpret_cast<const f32x4*>(wrow + g * H + k + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        __bf16 a, b;
+                        bf_split(v0[e], a, b); wh[g][c][e] = a; wl[g][c][e] = b;
+                        bf_split(v1[e], a, b); wh[g][c][4 + e] = a; wl[g][c][4 + e] = b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int k = kbase + 16 * c + 4 * kq;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (rlive && k + 3 < H) v = *reinterpret_cast<const f32x4*>(wrow + g * H + k);
+                    wf[g][c][0] = v[0]; wf[g][c][1] = v[1]; wf[g][c][2] = v[2]; wf[g][c][3] = v[3];
+                }
+            }
+        }
+    }
+
+    // sub-iteration q = ps * NQ + r * 3 + g reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1)
+    auto stage_issue = [&](int qn, u32x4 (&st)[PIECES]) {
+        const int psn = qn / NQ, rem = qn - psn * NQ;
+        const unsigned chunk = (unsigned)(((((psn - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + rem / 3) * 3 + rem % 3);
+        const unsigned base = chunk * (unsigned)Cf::CHUNK_BYTES;
+#pragma unroll
+        for (int e = 0; e < PIECES; ++e)
+            st[e] = __builtin_amdgcn_raw_buffer_load_b128(xr, base + (unsigned)(tid + 256 * e) * 16u, 0, AUX_SC1);
+    };
+    auto stage_commit = [&](int qn, const u32x4 (&st)[PIECES]) {
+        unsigned char* dst = smem + (qn & 1) * TILE;
+#pragma unroll
+        for (int e = 0; e < PIECES; ++e) {
+            const int i = tid + 256 * e;
+            *reinterpret_cast<u32x4*>(dst + (i / PPR) * RS + (i % PPR) * 16) = st[e];
+        }
+    };
+
+    struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
+    auto epi_load = [&](int ps, int r, int te, EpiIn& in) {
+        const int s = T - 1 - ps;
+        const int t = (dir == 0) ? s : T - 1 - s;
+        const int slot_prev = (dir == 0) ? t : t + 2;
+        const int tsel = KSPLIT == 2 ? kh : te;
+        const int b = m_base + 32 * r + 16 * tsel + n;
+        const int bc = b < B ? b : B - 1;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        in.keep = (u32x4){0u, 0u, 0u, 0u};
+        if (ps > 0) in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1);
+        else if (p.dhn) in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc));
+        if (ps < T) {
+            in.dy = p.dy ? *reinterpret_cast<const f32x4*>(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc) : z4;
+            const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+            in.rg = *reinterpret_cast<const f32x4*>(sv);
+            in.zg = *reinterpret_cast<const f32x4*>(sv + H);
+            in.ng = *reinterpret_cast<const f32x4*>(sv + 2 * H);
+            in.q = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+            in.hp = *reinterpret_cast<const f32x4*>(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
+        } else {
+            in.dy = z4; in.rg = z4; in.zg = z4; in.ng = z4; in.q = z4; in.hp = z4;
+        }
+    };
+    // gate gradients of processing step ps for (round r, this lane's trial and units); acc = dgh_{ps-1} W_hh (own units)
+    auto epilogue = [&](int ps, int r, int te, const EpiIn& in, const f32x4& acc) {
+        const int s = T - 1 - ps;
+        const int t = (dir == 0) ? s : T - 1 - s;
+        const int tsel = KSPLIT == 2 ? kh : te;
+        const int b = m_base + 32 * r + 16 * tsel + n;
+        const bool live = b < B && ulive;
+        f32x4 carry = __builtin_bit_cast(f32x4, in.keep);             // (whole vector: a bit_cast of ONE element reads element 0)
+        if (ps > 0) carry += acc;
+        if (ps == T) {
+            if (live && p.dh0) *reinterpret_cast<f32x4*>(p.dh0 + ((long long)dir * B + b) * H + ju) = carry;
+            return;
+        }
+        f32x4 dar, daz, dan, danr, keep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dh = in.dy[i] + carry[i];
+            const float r_ = in.rg[i], z_ = in.zg[i], n_ = in.ng[i];
+            const float dn = dh * (1.f - z_);
+            const float dz = dh * (in.hp[i] - n_);
+            const float da = dn * (1.f - n_ * n_);
+            daz[i] = live ? dz * z_ * (1.f - z_) : 0.f;
+            dar[i] = live ? da * in.q[i] * r_ * (1.f - r_) : 0.f;
+            dan[i] = da;
+            danr[i] = live ? da * r_ : 0.f;
+            keep[i] = dh * z_;
+        }
+        if (ps + 1 < p.ps_total) {                      // someone will contract these gradients
+            const unsigned chunk0 = (unsigned)((((ps & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r) * 3);
+            const unsigned rowoff = (unsigned)(16 * tsel + n) * (unsigned)(KP * 4);
+            const f32x4* gsrc[3] = {&dar, &daz, &danr};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const unsigned base = (chunk0 + g) * (unsigned)Cf::CHUNK_BYTES + rowoff;
+                if constexpr (BF) {
+                    bf16x4 sh, sl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split((*gsrc[g])[i], a, c); sh[i] = a; sl[i] = c; }
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, base + (unsigned)ju * 2u, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, base + KP * 2 + (unsigned)ju * 2u, 0, AUX_SC1);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *gsrc[g]), xr, base + (unsigned)ju * 4u, 0, AUX_SC1);
+                }
+            }
+        }
+        if (live) {
+            float* o = p.dgi + (((long long)dir * T + t) * B + b) * 3 * H + ju;
+            *reinterpret_cast<f32x4*>(o) = dar;
+            *reinterpret_cast<f32x4*>(o + H) = daz;
+            *reinterpret_cast<f32x4*>(o + 2 * H) = dan;
+            *reinterpret_cast<f32x4*>(p.dghn + (((long long)dir * T + t) * B + b) * H + ju) = danr;
+            *reinterpret_cast<f32x4*>(p.keep + ((long long)dir * B + b) * H + ju) = keep;
+        }
+    };
+
+    int ps0 = p.ps_begin;
+    if (ps0 == 0) {
+        // first processing step: no contraction, the running gradient starts from dhn (or zero)
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+            for (int te = 0; te < NTE; ++te) {
+                EpiIn in;
+                epi_load(0, r, te, in);
+                epilogue(0, r, te, in, (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+        }
+        ps0 = 1;
+        if (ps0 >= p.ps_end) return;
+        // drain, then publish every round of step 0 at once
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p.handoff && wave == 0 && lane < NR)
+            __hip_atomic_store(myflags + lane * 16 + cm.member, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 64; p.handoff && wave == 0 && r < NR; r += 64)
+            if (r + lane < NR) __hip_atomic_store(myflags + (r + lane) * 16 + cm.member, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    const int q_begin = ps0 * NQ, q_end = p.ps_end * NQ;
+    if (p.handoff && wave == 0) {
+        // the first two sub-iterations (round 0, segments 0 and 1) are loaded without a look-ahead poll
+        unsigned f0 = 0;
+        if (lane < p.CS) f0 = __hip_atomic_load(myflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cl_wait(myflags, (unsigned)ps0, p.CS, lane, lane < p.CS ? f0 : 0xffffffffu, p.status);
+    }
+    __syncthreads();
+    {
+        u32x4 st0[PIECES];
+        stage_issue(q_begin, st0);
+        stage_commit(q_begin, st0);
+    }
+    __syncthreads();
+
+    f32x4 acc[2];
+    EpiIn ein[NTE];
+    for (int q = q_begin; q < q_end; ++q) {
+        const int ps = q / NQ, rem = q - ps * NQ;
+        const int r = rem / 3, g = rem - 3 * r;
+        u32x4 st[PIECES];
+        const bool has_next = q + 1 < q_end;
+        if (has_next) stage_issue(q + 1, st);
+        const int q2 = q + 2;
+        const int ps2 = q2 / NQ, rem2 = q2 - ps2 * NQ;
+        const int r2 = rem2 / 3;
+        const bool do_poll = p.handoff && wave == 0 && q2 < q_end && rem2 % 3 == 0;
+        unsigned fl = 0xffffffffu;
+        if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g == 0) {
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = acc[0];
+        }
+        if (g == 1) {
+#pragma unroll
+            for (int te = 0; te < NTE; ++te) epi_load(ps, r, te, ein[te]);
+        }
+
+        const unsigned char* tb = smem + (q & 1) * TILE;
+        // the gate segment is a runtime value: select the register block with a uniform branch per segment
+        auto contract = [&](auto G) {
+            constexpr int gg = decltype(G)::value;
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    bf16x8 bh[2], bl[2];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const unsigned char* rp = tb + ((tt * 16 + n) * 2) * RS + (kbase + 32 * c + 8 * kq) * 2;
+                        bh[tt] = *reinterpret_cast<const bf16x8*>(rp);
+                        bl[tt] = *reinterpret_cast<const bf16x8*>(rp + RS);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[gg][c], bh[tt], acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[gg][c], bl[tt], acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[gg][c], bh[tt], acc[tt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    f32x4 a4[2];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * RS + (kbase + 16 * c + 4 * kq) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gg][c][e], a4[tt][e], acc[tt], 0, 0, 0);
+                }
+            }
+        };
+        if (g == 0) contract(std::integral_constant<int, 0>{});
+        else if (g == 1) contract(std::integral_constant<int, 1>{});
+        else contract(std::integral_constant<int, 2>{});
+
+        if constexpr (KSPLIT == 2) {
+            if (g == 2) {
+                unsigned char* xw = xch + ((q / 3) & 1) * (4 * 3 * 1024) + wave * (3 * 1024) + lane * 16;
+                *reinterpret_cast<f32x4*>(xw) = kh ? acc[0] : acc[1];
+            }
+        }
+        if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+        if (has_next) stage_commit(q + 1, st);
+        __syncthreads();
+        // publish the round whose gate gradients were stored at the end of the previous sub-iteration
+        if (p.handoff && tid == 0 && g == 0 && q > q_begin) {
+            const int qp = q - 1;
+            const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
+            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (g == 2) {
+#pragma unroll
+            for (int te = 0; te < NTE; ++te) {
+                const int tsel = KSPLIT == 2 ? kh : te;
+                f32x4 a = tsel ? acc[1] : acc[0];
+                if constexpr (KSPLIT == 2) {
+                    const unsigned char* xr_ = xch + ((q / 3) & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
+                    a += *reinterpret_cast<const f32x4*>(xr_);
+                }
+                epilogue(ps, r, te, ein[te], a);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+struct ClPlan {
+    bool ok;
+    int KSPLIT, KP, U, CS, nblk, Mc, NR, Bp, grid;
+    size_t flags_bytes, xbuf_fwd, xbuf_bwd, keep_bytes;
+};
+
+int cl_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return cus;
+    }();
+    return n;
+}
+
+// mode: 0 = off (per-step GEMM kernels of xps_gru.hip), 1 = cluster kernels one step per launch, 2 = persistent (default)
+int g_cluster_mode = -1;
+int cl_mode() {
+    if (g_cluster_mode < 0) {
+        const char* e = getenv("XPS_GRU_CLUSTER");
+        int m = 2;
+        if (e && (!strcmp(e, "off") || !strcmp(e, "0"))) m = 0;
+        else if (e && (!strcmp(e, "steps") || !strcmp(e, "1"))) m = 1;
+        g_cluster_mode = m;
+    }
+    return g_cluster_mode;
+}
+
+ClPlan cl_plan(int B, int H, int ndir) {
+    ClPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    if (cl_mode() == 0 || H <= 128 || H > 512 || (H % 4) != 0 || B < 128) return pl;
+    const int cus = cl_num_cus();
+    pl.KSPLIT = H > 256 ? 2 : 1;
+    pl.KP = 256 * pl.KSPLIT;
+    pl.U = 64 / pl.KSPLIT;
+    pl.CS = (H + pl.U - 1) / pl.U;
+    const int max_blk = cus / (pl.CS * ndir);
+    if (max_blk < 1) return pl;
+    int nblk = B / 128;                       // >= 4 rounds of 32 trials per cluster (the hand-off pipeline's depth)
+    if (nblk > max_blk) nblk = max_blk;
+    if (nblk < 1) return pl;
+    pl.nblk = nblk;
+    const int per = (B + nblk - 1) / nblk;
+    pl.Mc = ((per + 31) / 32) * 32;
+    pl.NR = pl.Mc / 32;
+    pl.Bp = pl.nblk * pl.Mc;
+    pl.grid = ndir * pl.nblk * pl.CS;
+    pl.flags_bytes = (((size_t)ndir * pl.nblk * pl.NR * 16 * 4 + 256 + 255) / 256) * 256;     // flags + the status word (last 256 B)
+    pl.xbuf_fwd = (size_t)2 * ndir * pl.Bp * pl.KP * 4;
+    pl.xbuf_bwd = 3 * pl.xbuf_fwd;
+    pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
+    pl.ok = pl.NR >= 4 && pl.xbuf_bwd < ((size_t)1 << 31);
+    return pl;
+}
+
+template <typename K>
+bool cl_set_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+
+inline bool cl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// ---- internal interface used by xps_gru.hip's entry points ----
+bool xps_internal_gru_cluster_usable(int B, int H, int ndir) { return cl_plan(B, H, ndir).ok; }
+
+size_t xps_internal_gru_cluster_fwd_workspace(int B, int H, int ndir) {
+    const ClPlan pl = cl_plan(B, H, ndir);
+    return pl.ok ? pl.flags_bytes + pl.xbuf_fwd : 0;
+}
+
+size_t xps_internal_gru_cluster_bwd_workspace(int B, int H, int ndir) {
+    const ClPlan pl = cl_plan(B, H, ndir);
+    return pl.ok ? pl.flags_bytes + pl.keep_bytes + pl.xbuf_bwd : 0;
+}
+
+size_t xps_internal_gru_cluster_status_offset(int B, int H, int ndir) {
+    const ClPlan pl = cl_plan(B, H, ndir);
+    return pl.ok ? pl.flags_bytes - 256 : 0;
+}
+
+int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh, const float* h0,
+                                 float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st) {
+    const ClPlan pl = cl_plan(B, H, ndir);
+    if (!pl.ok) { xps_set_error("gru cluster forward: unsupported shape"); return XPS_E_INVALID; }
+    const bool bf = xps_internal_gemm_mode() == 1;
+    ClFwd p;
+    p.gi = gi; p.y_ext = y_ext; p.saved = saved;
+    for (int d = 0; d < 2; ++d) { p.w_hh[d] = w_hh[d < ndir ? d : 0]; p.b_hh[d] = b_hh[d < ndir ? d : 0]; }
+    if (!cl_aligned16(gi) || !cl_aligned16(y_ext) || !cl_aligned16(saved) || !cl_aligned16(p.w_hh[0]) || !cl_aligned16(p.w_hh[1]) ||
+        !cl_aligned16(p.b_hh[0]) || !cl_aligned16(p.b_hh[1]) || !cl_aligned16(h0) || !cl_aligned16(workspace)) {
+        xps_set_error("gru cluster forward: operands must be 16-byte aligned");
+        return XPS_E_INVALID;
+    }
+    unsigned char* ws = (unsigned char*)workspace;
+    p.flags = (unsigned*)ws;
+    p.status = (unsigned*)(ws + pl.flags_bytes - 256);
+    p.xbuf = ws + pl.flags_bytes;
+    p.xbuf_bytes = (unsigned)pl.xbuf_fwd;
+    p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.Bp = pl.Bp; p.Mc = pl.Mc; p.NR = pl.NR; p.nblk = pl.nblk; p.CS = pl.CS;
+    if (hipMemsetAsync(ws, 0, pl.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster forward: memset failed"); return XPS_E_HIP; }
+    if (pl.CS * pl.U < pl.KP) {
+        // state columns no member owns (H far below KP) meet zero weights in the contraction: they must be finite
+        if (hipMemsetAsync(p.xbuf, 0, pl.xbuf_fwd, st) != hipSuccess) { xps_set_error("gru cluster forward: memset failed"); return XPS_E_HIP; }
+    }
+    {
+        const long long total = (long long)ndir * pl.Bp * (pl.KP / 4);
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        if (bf) hipLaunchKernelGGL(gru_cluster_init_kernel<true>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP);
+        else hipLaunchKernelGGL(gru_cluster_init_kernel<false>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP);
+    }
+    const bool persistent = cl_mode() == 2 && pl.grid <= cl_num_cus();
+    auto launch = [&](auto kernel, int lds) -> bool {
+        if (!cl_set_lds(kernel, lds)) return false;
+        if (persistent) {
+            p.s_begin = 0; p.s_end = T; p.handoff = 1;
+            hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+        } else {
+            p.handoff = 0;
+            for (int s = 0; s < T; ++s) {
+                p.s_begin = s; p.s_end = s + 1;
+                hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+            }
+        }
+        return true;
+    };
+    bool ok;
+    if (pl.KSPLIT == 2) ok = bf ? launch(gru_cluster_fwd_kernel<2, true>, ClCfg<2, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<2, false>, ClCfg<2, false, 1>::LDS_BYTES);
+    else ok = bf ? launch(gru_cluster_fwd_kernel<1, true>, ClCfg<1, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<1, false>, ClCfg<1, false, 1>::LDS_BYTES);
+    if (!ok) { xps_set_error("gru cluster forward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                                 const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                                 int T, int B, int H, int ndir, void* workspace, hipStream_t st) {
+    const ClPlan pl = cl_plan(B, H, ndir);
+    if (!pl.ok) { xps_set_error("gru cluster backward: unsupported shape"); return XPS_E_INVALID; }
+    const bool bf = xps_internal_gemm_mode() == 1;
+    ClBwd p;
+    p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
+    for (int d = 0; d < 2; ++d) p.w_hh_t[d] = w_hh_t[d < ndir ? d : 0];
+    if (!cl_aligned16(dy) || !cl_aligned16(dhn) || !cl_aligned16(y_ext) || !cl_aligned16(saved) || !cl_aligned16(p.w_hh_t[0]) ||
+        !cl_aligned16(p.w_hh_t[1]) || !cl_aligned16(dgi) || !cl_aligned16(dghn) || !cl_aligned16(dh0) || !cl_aligned16(workspace)) {
+        xps_set_error("gru cluster backward: operands must be 16-byte aligned");
+        return XPS_E_INVALID;
+    }
+    unsigned char* ws = (unsigned char*)workspace;
+    p.flags = (unsigned*)ws;
+    p.status = (unsigned*)(ws + pl.flags_bytes - 256);
+    p.keep = (float*)(ws + pl.flags_bytes);
+    p.xbuf = ws + pl.flags_bytes + pl.keep_bytes;
+    p.xbuf_bytes = (unsigned)pl.xbuf_bwd;
+    p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.Bp = pl.Bp; p.Mc = pl.Mc; p.NR = pl.NR; p.nblk = pl.nblk; p.CS = pl.CS;
+    if (hipMemsetAsync(ws, 0, pl.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster backward: memset failed"); return XPS_E_HIP; }
+    if (pl.CS * pl.U < pl.KP) {
+        // gate-gradient columns no member owns (H far below KP) are contracted with zero weights: they must be finite
+        if (hipMemsetAsync(p.xbuf, 0, pl.xbuf_bwd, st) != hipSuccess) { xps_set_error("gru cluster backward: memset failed"); return XPS_E_HIP; }
+    }
+    const int ps_total = T + (dh0 ? 1 : 0);
+    p.ps_total = ps_total;
+    const bool persistent = cl_mode() == 2 && pl.grid <= cl_num_cus();
+    auto launch = [&](auto kernel, int lds) -> bool {
+        if (!cl_set_lds(kernel, lds)) return false;
+        if (persistent) {
+            p.ps_begin = 0; p.ps_end = ps_total; p.handoff = 1;
+            hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+        } else {
+            p.handoff = 0;
+            for (int ps = 0; ps < ps_total; ++ps) {
+                p.ps_begin = ps; p.ps_end = ps + 1;
+                hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+            }
+        }
+        return true;
+    };
+    bool ok;
+    if (pl.KSPLIT == 2) ok = bf ? launch(gru_cluster_bwd_kernel<2, true>, ClCfg<2, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<2, false>, ClCfg<2, false, 3>::LDS_BYTES);
+    else ok = bf ? launch(gru_cluster_bwd_kernel<1, true>, ClCfg<1, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<1, false>, ClCfg<1, false, 3>::LDS_BYTES);
+    if (!ok) { xps_set_error("gru cluster backward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_set_gru_cluster_mode(int mode) {
+    if (mode < 0 || mode > 2) { xps_set_error("xps_set_gru_cluster_mode: mode must be 0 (off), 1 (one step per launch) or 2 (persistent)"); return XPS_E_INVALID; }
+    g_cluster_mode = mode;
+    return XPS_OK;
+}
+extern "C" int xps_get_gru_cluster_mode(void) { return cl_mode(); }

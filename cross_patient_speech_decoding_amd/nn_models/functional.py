@@ -275,12 +275,63 @@ def linear(x, w, b=None):
 # --------------------------------------------------------------------------- #
 # GRU                                                                          #
 # --------------------------------------------------------------------------- #
+_gru_ws_cache = {}
+
+
+def _gru_ws_bytes(fn, T, B, H, ndir):
+    """Workspace size of the recurrence entry points (depends on the shape and on the cluster mode only)."""
+    key = (fn, T, B, H, ndir, lib().xps_get_gru_cluster_mode())
+    n = _gru_ws_cache.get(key)
+    if n is None:
+        n = getattr(lib(), fn)(T, B, H, ndir)
+        if len(_gru_ws_cache) < 1024:
+            _gru_ws_cache[key] = n
+    return n
+
+
+# The cluster-persistent recurrence (128 < H <= 512) bounds every in-kernel wait; a wait that gave up sets a status word in
+# its workspace.  The words of the launches since the last check are kept (4-byte views) and read by check_gru_status(),
+# which the trainer calls where it synchronises anyway (when it reads the loss).
+_gru_status_words = []
+
+
+def _note_gru_status(ws, T, B, H, ndir):
+    off = lib().xps_gru_seq_status_offset(T, B, H, ndir)
+    if off >= 0:
+        if len(_gru_status_words) >= 64:
+            check_gru_status()
+        _gru_status_words.append(ws[off:off + 4])
+
+
+def check_gru_status():
+    """Synchronising check of the hand-off status words of the recurrence launches since the last call."""
+    if not _gru_status_words:
+        return
+    words = torch.cat(_gru_status_words).view(torch.int32)
+    _gru_status_words.clear()
+    if int(words.abs().sum().item()) != 0:
+        raise RuntimeError('xps_gru_seq: an in-kernel hand-off of the cluster-persistent GRU recurrence timed out (the GPU is '
+                           'shared with another persistent launch?); results are invalid.  XPS_GRU_CLUSTER=steps avoids '
+                           'in-kernel hand-offs')
+
+
+def set_gru_cluster_mode(name):
+    """'persistent' (default), 'steps' (same kernels, one step per launch) or 'off' (per-step GEMM kernels) for 128 < H <= 512."""
+    modes = {'off': 0, 'steps': 1, 'persistent': 2}
+    if name not in modes:
+        raise ValueError(f'gru cluster mode must be one of {sorted(modes)}')
+    call('xps_set_gru_cluster_mode', modes[name])
+
+
 def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save):
     dev = gi.device
     y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
     saved = torch.empty(ndir, T, B, 4 * H, dtype=_f32, device=dev) if save else None
+    nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', T, B, H, ndir)
+    ws = _ws(nbytes, dev)
     call('xps_gru_seq_fwd_f32', _ptr(gi), _ptr_array(w_hh), _ptr_array(b_hh), _ptr(h0), _ptr(y_ext),
-         _ptr(saved), T, B, H, ndir, _stream())
+         _ptr(saved), T, B, H, ndir, _ptr(ws), nbytes, _stream())
+    _note_gru_status(ws, T, B, H, ndir)
     return y_ext, saved
 
 
@@ -302,10 +353,11 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
     dgi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=dev)
     dghn = torch.empty(ndir, T, B, H, dtype=_f32, device=dev)
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
-    nbytes = lib().xps_gru_seq_bwd_f32_workspace(T, B, H, ndir)
+    nbytes = _gru_ws_bytes('xps_gru_seq_bwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
     call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
          _ptr(dghn), _ptr(dh0), T, B, H, ndir, _ptr(ws), nbytes, _stream())
+    _note_gru_status(ws, T, B, H, ndir)
     return dgi, dghn, dh0
 
 

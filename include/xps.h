@@ -125,9 +125,19 @@ int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, 
 /*          direction 1 runs t = T-1 .. 0                                       */
 /*   saved [ndir][T][B][4H]  r, z, n, (W_hn h + b_hn) for the backward (or NULL)  */
 /* ------------------------------------------------------------------------- */
+/* 128 < H <= 512 (H % 4 == 0, B >= 128): cluster-persistent recurrence (csrc/xps_gru_cluster.hip): W_hh stays in the registers
+ * of a cluster of workgroups for the whole sequence, the members exchange h_t through `workspace` inside ONE launch.
+ * xps_set_gru_cluster_mode / XPS_GRU_CLUSTER = off | steps | persistent (0 | 1 | 2, default 2): 1 runs the same kernels one
+ * step per launch, 0 the per-step GEMM kernels.  A hand-off that timed out (3 s; e.g. two such launches of different processes
+ * sharing one GPU) sets the 32-bit word at byte xps_gru_seq_status_offset() of the workspace to 1 (-1: the shape has no
+ * status word); the caller checks it whenever it synchronises anyway.                                                    */
+size_t xps_gru_seq_fwd_f32_workspace(int T, int B, int H, int ndir);
+long long xps_gru_seq_status_offset(int T, int B, int H, int ndir);
+int xps_set_gru_cluster_mode(int mode);
+int xps_get_gru_cluster_mode(void);
 int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
                         const float* h0, float* y_ext, float* saved,
-                        int T, int B, int H, int ndir, void* stream);
+                        int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward through the recurrence (BPTT).
  *   dy     [T][B][ndir*H]   gradient w.r.t. the layer output (actual time), or NULL (all zero)

@@ -29,7 +29,7 @@ def test_abi_version_and_error_channel(lib):
     assert b'xps_gemm_nt_f32' in lib.xps_last_error()
     with pytest.raises(_lib.XpsError, match='null argument'):
         _lib.call('xps_gemm_nn_f32', None, C.byref(rm), None, C.byref(rm), None, C.byref(rm), 4, 4, 4, 0, None)
-    rc = lib.xps_gru_seq_fwd_f32(None, None, None, None, None, None, 1, 1, 1, 1, None)
+    rc = lib.xps_gru_seq_fwd_f32(None, None, None, None, None, None, 1, 1, 1, 1, None, 0, None)
     assert rc == -1
 
 

@@ -79,7 +79,7 @@ def test_abi_refuses_unsupported_shapes():
     assert lib.xps_decoder_supported(128, 9, 3) == 1
     assert lib.xps_decoder_supported(500, 9, 3) == 0 and lib.xps_decoder_supported(128, 40, 3) == 0
     t = torch.zeros(16, device='cuda')
-    rc = lib.xps_gru_seq_fwd_f32(t.data_ptr(), None, None, None, t.data_ptr(), None, 1, 1, 4, 3, None)
+    rc = lib.xps_gru_seq_fwd_f32(t.data_ptr(), None, None, None, t.data_ptr(), None, 1, 1, 4, 3, None, 0, None)
     assert rc == -1 and b'null' in lib.xps_last_error()
     with pytest.raises(_lib.XpsError, match='1..8 streams'):
         _lib.call('xps_gemv_f32', t.data_ptr(), t.data_ptr(), None, t.data_ptr(), 4, 4, 9, None)

@@ -1,0 +1,184 @@
+"""GPU parity tests of the cluster-persistent GRU recurrence (csrc/xps_gru_cluster.hip; 128 < H <= 512, the
+north-star shape H = 512 and the reference default H = 500, nn_models/models.py:661-699, scripts/train_seq2seq.py:132):
+against torch.nn.GRU on the CPU (what the reference calls), and the three launch modes against each other --
+'persistent' (in-kernel hand-off between the workgroups of a cluster) must equal 'steps' (the same kernels, one
+launch per step: the kernel boundary is the hand-off) BIT FOR BIT, at full bench size, repeatedly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cross_patient_speech_decoding_amd import _build  # noqa: E402
+from cross_patient_speech_decoding_amd._lib import lib  # noqa: E402
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _built():
+    _build.build(verbose=False)
+    assert torch.cuda.is_available(), 'gpu tests need the MI355X'
+
+
+def XF():
+    from cross_patient_speech_decoding_amd.nn_models import functional
+    return functional
+
+
+@pytest.fixture
+def cluster_mode():
+    """Restores the launch mode of the recurrence after a test changed it."""
+    old = lib().xps_get_gru_cluster_mode()
+    yield XF().set_gru_cluster_mode
+    lib().xps_set_gru_cluster_mode(old)
+
+
+def _weights(gru, ndir):
+    out = []
+    for d in range(ndir):
+        sfx = '_l0' + ('_reverse' if d else '')
+        out += [getattr(gru, n + sfx).detach().clone() for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    return out
+
+
+def test_cluster_path_is_selected_for_the_north_star_shapes():
+    """The shapes this file is about really run the cluster kernels (a status word exists only there)."""
+    l = lib()
+    assert l.xps_get_gru_cluster_mode() == 2
+    for (T, B, H, ndir) in [(20, 2048, 512, 2), (20, 2048, 500, 2), (20, 256, 512, 2), (5, 150, 256, 2), (47, 2048, 256, 1)]:
+        assert l.xps_gru_seq_status_offset(T, B, H, ndir) >= 0, (T, B, H, ndir)
+        assert l.xps_gru_seq_fwd_f32_workspace(T, B, H, ndir) > 4096
+    for (T, B, H, ndir) in [(20, 2048, 128, 2), (20, 64, 512, 2), (20, 2048, 130, 2), (20, 2048, 640, 2)]:
+        assert l.xps_gru_seq_status_offset(T, B, H, ndir) == -1, (T, B, H, ndir)
+
+
+@pytest.mark.parametrize('mode', ['persistent', 'steps'])
+@pytest.mark.parametrize('T,B,In,H,ndir', [(6, 256, 24, 512, 2), (5, 200, 16, 500, 2), (4, 130, 12, 320, 1), (3, 300, 10, 256, 2),
+                                           (7, 160, 20, 192, 1), (2, 1030, 8, 388, 2)])
+def test_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir, mode, gemm_precision, cluster_mode):
+    """Whole layer (input projection + recurrence + BPTT + weight gradients) against torch.nn.GRU on the CPU; same
+    tolerances as the H <= 128 kernels (tests/test_gpu_nn_kernels.py)."""
+    cluster_mode(mode)
+    torch.set_num_threads(8)
+    torch.manual_seed(T * 100 + H)
+    gru = torch.nn.GRU(In, H, 1, batch_first=False, bidirectional=(ndir == 2))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, B, In, generator=g)
+    x_ref = x.clone().requires_grad_(True)
+    y_ref, hn_ref = gru(x_ref)
+    wt = torch.randn(T, B, ndir * H, generator=g)
+    (y_ref * wt).sum().backward()
+
+    xf = XF()
+    ws = [w.cuda().requires_grad_(True) for w in _weights(gru, ndir)]
+    xg = x.cuda().requires_grad_(True)
+    y, hn = xf.GRULayerFn.apply(xg, ndir, xf.HN_STACK, *ws)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), hn_ref.detach().numpy(), atol=2e-5)
+    (y * wt.cuda()).sum().backward()
+    xf.check_gru_status()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x_ref.grad.numpy(), atol=5e-5, rtol=1e-4)
+    names = []
+    for d in range(ndir):
+        sfx = '_l0' + ('_reverse' if d else '')
+        names += [n + sfx for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    for w, n in zip(ws, names):
+        ref = getattr(gru, n).grad.numpy()
+        tol = 2e-4 * max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(w.grad.cpu().numpy(), ref, atol=tol, rtol=1e-3, err_msg=n)
+
+
+@pytest.mark.parametrize('H,ndir', [(512, 2), (256, 1)])
+def test_recurrence_with_initial_state_and_its_gradient(H, ndir, gemm_precision):
+    """GRURecurFn with h0: exercises the h0 slots, the dhn-free start and the extra dh0 pass of the backward kernel."""
+    torch.set_num_threads(8)
+    T, B, In = 4, 192, 12
+    torch.manual_seed(3)
+    gru = torch.nn.GRU(In, H, 1, bidirectional=(ndir == 2))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, In, generator=g)
+    h0 = (0.5 * torch.randn(ndir, B, H, generator=g)).requires_grad_(True)
+    y_ref, hn_ref = gru(x, h0)
+    wt = torch.randn(T, B, ndir * H, generator=g)
+    (y_ref * wt).sum().backward()
+
+    xf = XF()
+    w = _weights(gru, ndir)
+    gi = torch.stack([torch.nn.functional.linear(x, w[4 * d], w[4 * d + 2]) for d in range(ndir)]).cuda()
+    h0g = h0.detach().cuda().requires_grad_(True)
+    wb = [w[4 * d + 1].cuda().requires_grad_(True) for d in range(ndir)] + [w[4 * d + 3].cuda().requires_grad_(True) for d in range(ndir)]
+    y_ext = xf.GRURecurFn.apply(gi, h0g, ndir, *wb)
+    y = y_ext[1:T + 1]
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5)
+    (y * wt.cuda()).sum().backward()
+    xf.check_gru_status()
+    np.testing.assert_allclose(h0g.grad.cpu().numpy(), h0.grad.numpy(), atol=5e-5, rtol=1e-4)
+    ref = gru.weight_hh_l0.grad.numpy()
+    np.testing.assert_allclose(wb[0].grad.cpu().numpy(), ref, atol=2e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-3)
+
+
+def _run_layer(xf, x, ws, wt, ndir):
+    xg = x.clone().requires_grad_(True)
+    wl = [w.clone().requires_grad_(True) for w in ws]
+    y, hn = xf.GRULayerFn.apply(xg, ndir, xf.HN_STACK, *wl)
+    (y * wt).sum().backward()
+    torch.cuda.synchronize()
+    xf.check_gru_status()
+    return [y.detach().clone(), hn.detach().clone(), xg.grad.clone()] + [w.grad.clone() for w in wl]
+
+
+@pytest.mark.parametrize('H', [512, 500])
+def test_persistent_equals_one_launch_per_step_bitwise_full_size(H, gemm_precision, cluster_mode):
+    """Bench-size layer (2048 trials x 20 steps, bidirectional: the per-GPU shard of configs[3]): the in-kernel
+    hand-off ('persistent') and the kernel-boundary hand-off ('steps') run the same arithmetic, so EVERY output bit
+    must agree -- a stale or early read of the exchange buffer shows up here.  Three launches of each (the second
+    and third start with warm caches) and a memory-heavy kernel in between (uneven load)."""
+    xf = XF()
+    T, B, In, ndir = 20, 2048, 30, 2
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(T, B, In, generator=g).cuda()
+    wt = torch.randn(T, B, ndir * H, generator=g).cuda()
+    torch.manual_seed(4)
+    gru = torch.nn.GRU(In, H, 1, bidirectional=True)
+    ws = [w.cuda() for w in _weights(gru, ndir)]
+    cluster_mode('steps')
+    ref = _run_layer(xf, x, ws, wt, ndir)
+    assert all(torch.isfinite(r).all() for r in ref)
+    junk = torch.empty(64 << 20, device='cuda')
+    cluster_mode('persistent')
+    for rep in range(3):
+        junk.normal_()                                  # streams 256 MB through L2 / Infinity Cache between the launches
+        out = _run_layer(xf, x, ws, wt, ndir)
+        for a, b, name in zip(out, ref, ['y', 'hn', 'dx'] + ['w%d' % i for i in range(8)]):
+            assert torch.equal(a, b), f'{name} differs between persistent and per-step launches (repeat {rep})'
+    cluster_mode('off')
+    old = _run_layer(xf, x, ws, wt, ndir)               # the per-step GEMM kernels: same math, other summation order
+    np.testing.assert_allclose(old[0].cpu().numpy(), ref[0].cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(old[2].cpu().numpy(), ref[2].cpu().numpy(), atol=1e-4, rtol=1e-3)
+
+
+def test_persistent_under_concurrent_load(cluster_mode):
+    """The hand-off while another stream keeps the memory system busy and takes CUs away (uneven load): results
+    still equal the per-step launches bit for bit."""
+    xf = XF()
+    T, B, In, H, ndir = 12, 1024, 16, 512, 2
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(T, B, In, generator=g).cuda()
+    wt = torch.randn(T, B, ndir * H, generator=g).cuda()
+    torch.manual_seed(9)
+    gru = torch.nn.GRU(In, H, 1, bidirectional=True)
+    ws = [w.cuda() for w in _weights(gru, ndir)]
+    cluster_mode('steps')
+    ref = _run_layer(xf, x, ws, wt, ndir)
+    cluster_mode('persistent')
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device='cuda')
+    big = torch.empty(32 << 20, device='cuda')
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big.add_(1.0)
+                a = torch.tanh(a @ a * 1e-3)
+        out = _run_layer(xf, x, ws, wt, ndir)
+        side.synchronize()
+        for p, q in zip(out, ref):
+            assert torch.equal(p, q), f'repeat {rep}'
