@@ -57,24 +57,78 @@ struct ClCfg {
     static constexpr int KSEGS = KSEG;                       // gate segments of the contraction (forward 1, backward 3)
 };
 
+#ifdef XPS_CL_STAMP
+// Diagnostic build only (tools/stamp_cluster.py; never shipped): per-wave cycle sums of the loop segments, written to a
+// buffer of their own that no kernel reads.
+__device__ unsigned long long g_clstamp[2 * 1024 * 8];
+#define CL_STAMP(var)                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);
+#define CL_ACC(sum, a, b) sum += (b) - (a);
+#else
+#define CL_STAMP(var)
+#define CL_ACC(sum, a, b)
+#endif
+
 __device__ inline float cl_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ inline float cl_tanh(float x) { return 2.0f * cl_sigmoid(2.0f * x) - 1.0f; }
 
-// one wave polls the CS flags of a round until every member has published `need`; bounded (3 s)
+// one wave polls the CS flags of a round until every member has published `need`; bounded (3 s).  Slow path only (the
+// look-ahead poll found the round unpublished): status[1] counts such waits, status[2] sums and status[3] keeps the longest
+// of them in 10 ns ticks (diagnostics read by tools/bench_gru.py; status[0] != 0 means a wait gave up).
 __device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int lane, unsigned first, unsigned* status) {
     unsigned v = first;
     if (__all(v >= need)) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    bool ok = false;
     for (;;) {
         v = need;
         if (lane < cs) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v >= need)) return;
-        __builtin_amdgcn_s_sleep(4);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
-            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+        if (__all(v >= need)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) break;
+    }
+    if (lane == 0) {
+        const unsigned dt = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);
+        if (!ok) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(status + 2, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(status + 3, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Are all members of this cluster on ONE XCD?  Verified at run time, never assumed from blockIdx: every member publishes
+// its XCC id, one wave collects the CS ids.  Same XCD: the members share an L2, so exchange stores may stay write-back
+// (plain) and the sc1 loads (which bypass L1 only) hit that L2 instead of going to the memory side.  Otherwise every
+// exchange store is write-through (sc1).  All members read the same table, so the whole cluster takes the same decision.
+__device__ inline bool cl_same_xcd(unsigned* tab, int member, int cs, int lane, int wave, unsigned* status, unsigned* lds_word) {
+    if (wave == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        id = (id & 15u) + 1u;
+        if (lane == 0) __hip_atomic_store(tab + member, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned v = id;
+        bool ok = false;
+        for (;;) {
+            v = id;
+            if (lane < cs) v = __hip_atomic_load(tab + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v != 0u)) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) break;
+        }
+        if (!ok && lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool same = ok && __all(v == id);
+        if (lane == 0) {
+            *lds_word = same ? 1u : 0u;
+            __hip_atomic_fetch_add(status + (same ? 4 : 5), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostics: workgroups on the one-XCD / mixed path
         }
     }
+    __syncthreads();
+    const bool r = *lds_word != 0u;
+    __syncthreads();
+    return r;
 }
 
 struct ClMap { int cluster, member; };
@@ -104,6 +158,7 @@ struct ClFwd {
     float* saved;
     void* xbuf;            // [2 parity][ndir][Bp] rows of KP elements (bf16 hi plane + lo plane, or f32)
     unsigned* flags;       // [cluster][NR][16]
+    unsigned* xcc;         // [cluster][16]  XCC id + 1 of every member (cl_same_xcd)
     unsigned* status;
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
@@ -195,6 +250,8 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
         }
     };
 
+    // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave, p.status, reinterpret_cast<unsigned*>(smem));
     const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
     {
         u32x4 st0[PIECES];
@@ -321,10 +378,17 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(o[i], a, c); sh[i] = a; sl[i] = c; }
                     const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                    if (fast) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                    }
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, row * (unsigned)(KP * 4) + (unsigned)ju * 4u, 0, AUX_SC1);
+                    const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
+                    if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, AUX_SC1);
                 }
             }
             if (live && ulive) {
@@ -391,6 +455,7 @@ struct ClBwd {
     float* keep;                // [ndir][B][H]  z * dh of the step processed before
     void* xbuf;                 // [2 parity][ndir][Bp/32][3 gates][32 trials] rows of KP elements
     unsigned* flags;
+    unsigned* xcc;
     unsigned* status;
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
@@ -419,6 +484,10 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
     const int ldy = p.ndir * H;
     const int m_base = blk * p.Mc;
     const int NQ = 3 * NR;                              // sub-iterations (round, gate segment) per processing step
+#ifdef XPS_CL_STAMP
+    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
+    rt[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const float* __restrict__ WT = p.w_hh_t[dir];
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
@@ -476,6 +545,14 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
             *reinterpret_cast<u32x4*>(dst + (i / PPR) * RS + (i % PPR) * 16) = st[e];
         }
     };
+
+#ifdef XPS_CL_STAMP
+    rt[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave, p.status, reinterpret_cast<unsigned*>(smem));
+#ifdef XPS_CL_STAMP
+    rt[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
     auto epi_load = [&](int ps, int r, int te, EpiIn& in) {
@@ -539,10 +616,16 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
                     bf16x4 sh, sl;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split((*gsrc[g])[i], a, c); sh[i] = a; sl[i] = c; }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, base + (unsigned)ju * 2u, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, base + KP * 2 + (unsigned)ju * 2u, 0, AUX_SC1);
+                    if (fast) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, base + (unsigned)ju * 2u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, base + KP * 2 + (unsigned)ju * 2u, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, base + (unsigned)ju * 2u, 0, AUX_SC1);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, base + KP * 2 + (unsigned)ju * 2u, 0, AUX_SC1);
+                    }
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *gsrc[g]), xr, base + (unsigned)ju * 4u, 0, AUX_SC1);
+                    if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *gsrc[g]), xr, base + (unsigned)ju * 4u, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *gsrc[g]), xr, base + (unsigned)ju * 4u, 0, AUX_SC1);
                 }
             }
         }
@@ -578,6 +661,9 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
             if (r + lane < NR) __hip_atomic_store(myflags + (r + lane) * 16 + cm.member, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+#ifdef XPS_CL_STAMP
+    rt[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int q_begin = ps0 * NQ, q_end = p.ps_end * NQ;
     if (p.handoff && wave == 0) {
         // the first two sub-iterations (round 0, segments 0 and 1) are loaded without a look-ahead poll
@@ -595,9 +681,15 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
 
     f32x4 acc[2];
     EpiIn ein[NTE];
+#ifdef XPS_CL_STAMP
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, a_issue = 0, a_mfma = 0, a_poll = 0, a_commit = 0, a_bar = 0, a_epi = 0, c_begin = 0, c_end = 0;
+    CL_STAMP(c_begin)
+    rt[4] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int q = q_begin; q < q_end; ++q) {
         const int ps = q / NQ, rem = q - ps * NQ;
         const int r = rem / 3, g = rem - 3 * r;
+        CL_STAMP(c0)
         u32x4 st[PIECES];
         const bool has_next = q + 1 < q_end;
         if (has_next) stage_issue(q + 1, st);
@@ -616,6 +708,7 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
             for (int te = 0; te < NTE; ++te) epi_load(ps, r, te, ein[te]);
         }
 
+        CL_STAMP(c1)
         const unsigned char* tb = smem + (q & 1) * TILE;
         // the gate segment is a runtime value: select the register block with a uniform branch per segment
         auto contract = [&](auto G) {
@@ -662,9 +755,13 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
                 *reinterpret_cast<f32x4*>(xw) = kh ? acc[0] : acc[1];
             }
         }
+        CL_STAMP(c2)
         if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+        CL_STAMP(c3)
         if (has_next) stage_commit(q + 1, st);
+        CL_STAMP(c4)
         __syncthreads();
+        CL_STAMP(c5)
         // publish the round whose gate gradients were stored at the end of the previous sub-iteration
         if (p.handoff && tid == 0 && g == 0 && q > q_begin) {
             const int qp = q - 1;
@@ -684,7 +781,19 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
             }
             asm volatile("" ::: "memory");
         }
+        CL_STAMP(c6)
+        CL_ACC(a_issue, c0, c1) CL_ACC(a_mfma, c1, c2) CL_ACC(a_poll, c2, c3) CL_ACC(a_commit, c3, c4) CL_ACC(a_bar, c4, c5) CL_ACC(a_epi, c5, c6)
     }
+#ifdef XPS_CL_STAMP
+    CL_STAMP(c_end)
+    if (lane == 0) {
+        const int wid = (blockIdx.x * 4 + wave) & 1023;
+        g_clstamp[wid * 8 + 0] = a_issue; g_clstamp[wid * 8 + 1] = a_mfma; g_clstamp[wid * 8 + 2] = a_poll; g_clstamp[wid * 8 + 3] = a_commit;
+        g_clstamp[wid * 8 + 4] = a_bar; g_clstamp[wid * 8 + 5] = a_epi; g_clstamp[wid * 8 + 6] = c_begin; g_clstamp[wid * 8 + 7] = c_end;
+        rt[5] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 6; ++i) g_clstamp[8192 + wid * 8 + i] = rt[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -739,7 +848,8 @@ ClPlan cl_plan(int B, int H, int ndir) {
     pl.NR = pl.Mc / 32;
     pl.Bp = pl.nblk * pl.Mc;
     pl.grid = ndir * pl.nblk * pl.CS;
-    pl.flags_bytes = (((size_t)ndir * pl.nblk * pl.NR * 16 * 4 + 256 + 255) / 256) * 256;     // flags + the status word (last 256 B)
+    // header: flags [cluster][NR][16], XCC table [cluster][16], padding, status block (last 256 B); zeroed before every launch
+    pl.flags_bytes = (((size_t)ndir * pl.nblk * (pl.NR + 1) * 16 * 4 + 256 + 255) / 256) * 256;
     pl.xbuf_fwd = (size_t)2 * ndir * pl.Bp * pl.KP * 4;
     pl.xbuf_bwd = 3 * pl.xbuf_fwd;
     pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
@@ -789,6 +899,7 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
     }
     unsigned char* ws = (unsigned char*)workspace;
     p.flags = (unsigned*)ws;
+    p.xcc = p.flags + (size_t)ndir * pl.nblk * pl.NR * 16;
     p.status = (unsigned*)(ws + pl.flags_bytes - 256);
     p.xbuf = ws + pl.flags_bytes;
     p.xbuf_bytes = (unsigned)pl.xbuf_fwd;
@@ -843,6 +954,7 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     }
     unsigned char* ws = (unsigned char*)workspace;
     p.flags = (unsigned*)ws;
+    p.xcc = p.flags + (size_t)ndir * pl.nblk * pl.NR * 16;
     p.status = (unsigned*)(ws + pl.flags_bytes - 256);
     p.keep = (float*)(ws + pl.flags_bytes);
     p.xbuf = ws + pl.flags_bytes + pl.keep_bytes;
@@ -877,6 +989,12 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }
+
+#ifdef XPS_CL_STAMP
+extern "C" int xps_debug_read_cluster_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clstamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int xps_set_gru_cluster_mode(int mode) {
     if (mode < 0 || mode > 2) { xps_set_error("xps_set_gru_cluster_mode: mode must be 0 (off), 1 (one step per launch) or 2 (persistent)"); return XPS_E_INVALID; }

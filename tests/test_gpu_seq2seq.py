@@ -210,3 +210,70 @@ def test_fused_decoder_equals_composed_path_and_oracle(H, B):
             assert (grads[k] - p.grad).abs().max().item() <= tol + 2e-3 * p.grad.abs().max().item(), (fused, k)
     # fused and composed agree with each other far below the oracle tolerance
     assert (results[True][0] - results[False][0]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize('H', [512, 500])
+def test_north_star_model_shape_vs_oracle(H, gemm_precision):
+    """configs[3] model shape (aligned d = 30 input channels, F = 100, 2-layer bidirectional GRU encoder with H = 512 --
+    and H = 500, the reference script's default, scripts/train_seq2seq.py:132 / nn_models/models.py:661-663 -- 1-layer
+    decoder), B = 256 trials: eval logits <= 1e-4 with identical argmax, then ONE full training step (teacher forcing
+    mixed, no dropout): logits, loss, every parameter gradient, clipped gradient norm and the AdamW-updated weights
+    against the CPU oracle.  The encoder runs the cluster-persistent recurrence (csrc/xps_gru_cluster.hip)."""
+    from oracle.seq2seq_oracle import Seq2SeqOracle
+    from cross_patient_speech_decoding_amd._lib import lib
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    torch.set_num_threads(16)
+    B, C = 256, 30
+    assert lib().xps_gru_seq_status_offset(20, B, H, 2) >= 0          # this shape runs the cluster kernels
+    cfg = dict(in_channels=C, n_filters=100, hidden_size=H, n_enc_layers=2, n_dec_layers=1, kernel_size=10,
+               stride=10, activation=False)
+    orc = Seq2SeqOracle(C, 100, H, 9, 2, 1, 10, 10, 0, 0.0, 0.0, learning_rate=1e-3, l2_reg=1e-5, activation=False)
+    orc.load_state_dict(weights_from_seed(orc.state_dict(), 40 + H))
+    m = build_hip(cfg, 40 + H)
+    rng = np.random.default_rng(H)
+    x = torch.from_numpy(rng.standard_normal((B, 200, C)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 9, (B, 3)))
+    orc.eval(); m.eval()
+    with torch.no_grad():
+        ref = orc(x, y, teacher_forcing_ratio=0)
+        out = m(x.cuda(), y.cuda(), teacher_forcing_ratio=0)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4
+    assert torch.equal(out.argmax(-1).cpu(), ref.argmax(-1))                  # all 768 argmax indices identical
+    orc.train(); m.train()
+    coins = [True, False, True]
+    opt_ref, _ = orc.make_optimizer()
+    opt_ref.zero_grad()
+    ref = orc(x, y, coins=coins)
+    loss_ref = torch.nn.functional.cross_entropy(ref.reshape(-1, 9), y.reshape(-1))
+    loss_ref.backward()
+    g_ref = {k: p.grad.detach().clone() for k, p in orc.named_parameters()}
+    gn_ref = float(torch.nn.utils.clip_grad_norm_(orc.parameters(), 0.5))
+    opt_ref.step()
+    opt = FlatAdamW(m, lr=1e-3, weight_decay=1e-5, max_norm=0.5)
+    opt.zero_grad()
+    out = m(x.cuda(), y.cuda(), coins=coins)
+    loss = m.criterion(out.view(-1, 9), y.cuda().view(-1))
+    loss.backward()
+    XF.check_gru_status()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4
+    np.testing.assert_allclose(float(loss.detach()), float(loss_ref.detach()), rtol=1e-5)
+    grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    for k, g in g_ref.items():
+        if k == NOISE_KEY:
+            continue
+        tol = (1e-4 if gemm_precision == 'fp32' else 3e-4) * max(float(g.abs().max()), 1e-6)
+        assert (grads[k] - g).abs().max().item() <= tol, (k, (grads[k] - g).abs().max().item(), tol)
+    opt.step()
+    np.testing.assert_allclose(float(opt.grad_norm()), gn_ref, rtol=2e-4)
+    refs = dict(orc.named_parameters())
+    for k, p in m.named_parameters():
+        if k == NOISE_KEY:
+            continue
+        got, want = p.detach().cpu().numpy(), refs[k].detach().numpy()
+        # Adam's first step moves a weight by lr * g / (|g| + eps) ~ lr * sign(g): an element whose gradient sits at the
+        # rounding-noise floor (1e-3 of the tensor's largest and below) can move the other way; the rest is compared
+        gr = g_ref[k].abs().numpy()
+        keep = gr > 1e-3 * gr.max()
+        got, want = got[keep], want[keep]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5, err_msg=k)
