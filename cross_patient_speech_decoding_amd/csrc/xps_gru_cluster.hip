@@ -45,16 +45,24 @@ struct ClCfg {
     static constexpr int KP = 256 * KSPLIT;                  // padded hidden size (k extent of one gate segment)
     static constexpr int NUT = 4 / KSPLIT;                   // 16-unit tiles per workgroup
     static constexpr int U = 16 * NUT;                       // hidden units per workgroup
-    static constexpr int ROWB = BF ? KP * 2 : KP * 4;        // bytes of one LDS row: one trial (and one plane: hi or lo)
-    static constexpr int RS = BF ? ROWB + 16 : ROWB + 32;    // row stride: trials 8 dwords (mod 64) apart -> conflict-free b128 reads
-    static constexpr int NROW = BF ? 64 : 32;
-    static constexpr int TILE_BYTES = NROW * RS;             // LDS image of one round's operand (32 trials x KP)
-    static constexpr int CHUNK_BYTES = 32 * KP * 4;          // the same in global memory: [trial32][plane][KP] bf16 or [trial32][KP] f32
-    static constexpr int PIECES = CHUNK_BYTES / 16 / 256;    // 16-byte pieces per thread
-    static constexpr int PPR = ROWB / 16;                    // pieces per row
+    // One round's operand (32 trials x KP, bf16 hi plane + lo plane or f32: 4 bytes per element either way) is moved by
+    // LDS-DMA in 1-KiB pieces (one wave instruction: 64 lanes x 16 B, contiguous in LDS).  Global order of a round:
+    // [trial32][plane][KP] bf16 / [trial32][KP] f32.  LDS image: trials TS bytes apart with TS = 8 dwords (mod 64): the
+    // b128 fragment reads of 16 trials x 4 k-quarters are bank-conflict free; pads sit between pieces.
+    static constexpr int CHUNK_BYTES = 32 * KP * 4;          // one round in global memory
+    static constexpr int NPIECE = CHUNK_BYTES / 1024;        // DMA pieces per round (64 or 32)
+    static constexpr int TRIAL_BYTES = KP * 4;               // 2048 or 1024
+    static constexpr int PPT = TRIAL_BYTES / 1024;           // pieces per trial (2 or 1)
+    static constexpr int TS = TRIAL_BYTES + 32;              // trial stride in LDS (2080 or 1056)
+    static constexpr int PS = BF ? (PPT == 2 ? 1040 : 512) : 0;            // plane stride (bf16): KP = 512: its own padded piece
+    static constexpr int TILE_BYTES = 32 * TS;
     static constexpr int XCH_BYTES = KSPLIT == 2 ? 2 * 4 * 3 * 1024 : 0;   // partial-sum swap, double buffered
     static constexpr int LDS_BYTES = 2 * TILE_BYTES + XCH_BYTES;
     static constexpr int KSEGS = KSEG;                       // gate segments of the contraction (forward 1, backward 3)
+    // LDS offset of DMA piece j inside a round image
+    __host__ __device__ static constexpr int piece_off(int j) {
+        return PPT == 2 ? (j >> 1) * TS + (j & 1) * (BF ? PS : 1024) : j * TS;
+    }
 };
 
 #ifdef XPS_CL_STAMP
@@ -147,6 +155,58 @@ __device__ inline ClMap cl_map(int CS) {
     return m;
 }
 
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses (L1 bypassed: sc1) to LDS [lds_dst, +1024).
+// Inline asm so that the compiler does not order its LDS reads of the OTHER buffer behind it; completion is waited for
+// by hand (s_waitcnt vmcnt(0) before the round's barrier).  M0 is saved and restored (compiler-reserved).
+__device__ inline void cl_dma_piece(const unsigned char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst));
+}
+
+__device__ inline unsigned cl_lds_base(const unsigned char* smem) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) unsigned char*)smem;
+}
+
+// resident weight fragments of one wave: rows = units j0 + n of `wsrc` rows (row stride ld floats), three k segments of 256
+template <bool BF>
+struct ClWeights {
+    bf16x8 wh[BF ? 3 : 1][BF ? 8 : 1], wl[BF ? 3 : 1][BF ? 8 : 1];
+    float wf[BF ? 1 : 3][BF ? 1 : 16][4];
+    // seg_ptr(g): first element of segment g in this lane's row; kvalid: number of valid k from there (multiple of 4, <= 256)
+    __device__ inline void load(const float* const (&seg)[3], bool rlive, int kq, int kvalid, const float* safe) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = 32 * c + 8 * kq;
+                    const bool ok0 = rlive && k + 3 < kvalid, ok1 = rlive && k + 7 < kvalid;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(ok0 ? seg[g] + k : safe);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(ok1 ? seg[g] + k + 4 : safe);
+                    if (!ok0) v0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!ok1) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        __bf16 a, b;
+                        bf_split(v0[e], a, b); wh[g][c][e] = a; wl[g][c][e] = b;
+                        bf_split(v1[e], a, b); wh[g][c][4 + e] = a; wl[g][c][4 + e] = b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int k = 16 * c + 4 * kq;
+                    const bool ok = rlive && k + 3 < kvalid;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(ok ? seg[g] + k : safe);
+                    if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    wf[g][c][0] = v[0]; wf[g][c][1] = v[1]; wf[g][c][2] = v[2]; wf[g][c][3] = v[3];
+                }
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
@@ -165,13 +225,21 @@ struct ClFwd {
     int s_begin, s_end, handoff;
 };
 
+// Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster).  Between two barriers a wave
+//   (1) publishes the round whose exchange stores were drained before the previous barrier,
+//   (2) runs the gate math of round it - 1 (its own k-half of the products kept in registers, the other half read from LDS),
+//       stores the outputs and the exchange rows,
+//   (3) requests the gate inputs of round it and the flags of round it + 2,
+//   (4) contracts round it (buffer it & 1) while its LDS-DMA pieces of round it + 1 stream into the other buffer,
+//   (5) waits for everything it issued (vmcnt(0)): DMA landed, stores complete; then the barrier.
 template <int KSPLIT, bool BF>
 __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
     using Cf = ClCfg<KSPLIT, BF, 1>;
-    constexpr int KP = Cf::KP, RS = Cf::RS, PIECES = Cf::PIECES, PPR = Cf::PPR, TILE = Cf::TILE_BYTES;
+    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 4;
     constexpr int NTE = KSPLIT == 2 ? 1 : 2;          // trial tiles whose gate math this wave runs per round
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xch = smem + 2 * TILE;
+    const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -192,103 +260,155 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y_ext, 0, (unsigned)((long long)(T + 2) * B * ldy * 4), RSRC_FLAGS);
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
 
-    // ---- resident weights: A operand rows = units j0 + n of gate g, k = kbase + ... ----
-    bf16x8 wh[BF ? 3 : 1][BF ? 8 : 1], wl[BF ? 3 : 1][BF ? 8 : 1];
-    float wf[BF ? 1 : 3][BF ? 1 : 16][4];
+    ClWeights<BF> w;
     {
         const int jr = j0 + n;
         const bool rlive = jr < H;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const float* wrow = W + (long long)(g * H + (rlive ? jr : 0)) * H;
-            if constexpr (BF) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int k = kbase + 32 * c + 8 * kq;
-                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                    if (rlive && k + 3 < H) v0 = *reinterpret_cast<const f32x4*>(wrow + k);
-                    if (rlive && k + 7 < H) v1 = *reinterpret_cast<const f32x4*>(wrow + k + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        __bf16 a, b;
-                        bf_split(v0[e], a, b); wh[g][c][e] = a; wl[g][c][e] = b;
-                        bf_split(v1[e], a, b); wh[g][c][4 + e] = a; wl[g][c][4 + e] = b;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int k = kbase + 16 * c + 4 * kq;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (rlive && k + 3 < H) v = *reinterpret_cast<const f32x4*>(wrow + k);
-                    wf[g][c][0] = v[0]; wf[g][c][1] = v[1]; wf[g][c][2] = v[2]; wf[g][c][3] = v[3];
-                }
-            }
-        }
+        const int jrc = rlive ? jr : 0;
+        const float* const seg[3] = {W + (long long)(0 * H + jrc) * H + kbase, W + (long long)(1 * H + jrc) * H + kbase,
+                                     W + (long long)(2 * H + jrc) * H + kbase};
+        w.load(seg, rlive, kq, H - kbase, W);
     }
     f32x4 bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        bias[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ulive) bias[g] = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + g * H + ju);
+        bias[g] = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + g * H + juc);
+        if (!ulive) bias[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-
-    // ---- operand staging: global (sc1) -> registers -> LDS image of iteration itn ----
-    auto stage_issue = [&](int itn, u32x4 (&st)[PIECES]) {
-        const int sn = itn / NR, rn = itn - sn * NR;
-        const unsigned base = (unsigned)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (unsigned)(KP * 4);
-#pragma unroll
-        for (int e = 0; e < PIECES; ++e)
-            st[e] = __builtin_amdgcn_raw_buffer_load_b128(xr, base + (unsigned)(tid + 256 * e) * 16u, 0, AUX_SC1);
-    };
-    auto stage_commit = [&](int itn, const u32x4 (&st)[PIECES]) {
-        unsigned char* dst = smem + (itn & 1) * TILE;
-#pragma unroll
-        for (int e = 0; e < PIECES; ++e) {
-            const int i = tid + 256 * e;
-            *reinterpret_cast<u32x4*>(dst + (i / PPR) * RS + (i % PPR) * 16) = st[e];
-        }
-    };
 
     // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
     const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave, p.status, reinterpret_cast<unsigned*>(smem));
+
+    // this wave's share of round itn's operand: PPW pieces -> buffer itn & 1
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+    auto dma_src = [&](int itn) -> const unsigned char* {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        return xb + (size_t)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (KP * 4) + (size_t)(wave * PPW) * 1024 + lane * 16;
+    };
+    auto dma_piece = [&](const unsigned char* src, int itn, int i) {      // i = 0 .. PPW - 1 (compile time at every call site)
+        // the piece index is wave * PPW + i; PPW is even, so the plane / half of a piece is that of i
+        const unsigned dst = lds0 + (unsigned)((itn & 1) * TILE) +
+                             (unsigned)(Cf::PPT == 2 ? ((wave * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (wave * PPW + i) * TS);
+        cl_dma_piece(src + i * 1024, dst);
+    };
+
     const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
     {
-        u32x4 st0[PIECES];
-        stage_issue(it_begin, st0);
-        stage_commit(it_begin, st0);
+        const unsigned char* src = dma_src(it_begin);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(src, it_begin, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    for (int it = it_begin; it < it_end; ++it) {
-        const int s = it / NR, r = it - s * NR;
-        const int t = (dir == 0) ? s : T - 1 - s;
+    // gate inputs of a round (requested one round before they are used)
+    struct EpiIn { f32x4 gr, gz, gn; u32x4 hp; };
+    auto epi_load = [&](int itn, int te, EpiIn& in) {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        const int t = (dir == 0) ? sn : T - 1 - sn;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        // (A) requests: next round's operand, this round's gate inputs, the flags of the round after next
-        u32x4 st[PIECES];
-        const bool has_next = it + 1 < it_end;
-        if (has_next) stage_issue(it + 1, st);
+        const int tsel = KSPLIT == 2 ? kh : te;
+        const int b = m_base + 32 * rn + 16 * tsel + n;
+        const int bc = b < B ? b : B - 1;
+        const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
+        in.gr = *reinterpret_cast<const f32x4*>(gp);
+        in.gz = *reinterpret_cast<const f32x4*>(gp + H);
+        in.gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+        // own previous state (fp32), written by this lane one step ago (or by the init kernel)
+        in.hp = __builtin_amdgcn_raw_buffer_load_b128(yr, (unsigned)((((long long)slot_prev * B + bc) * ldy + dir * H + juc) * 4), 0, AUX_SC1);
+    };
+    // gates + hidden update of round itn for this lane's trial and four units; a_* = complete pre-activation products
+    auto epilogue = [&](int itn, int te, const EpiIn& in, f32x4 a_r, f32x4 a_z, f32x4 a_n) {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        const int t = (dir == 0) ? sn : T - 1 - sn;
+        const int tsel = KSPLIT == 2 ? kh : te;
+        const int b = m_base + 32 * rn + 16 * tsel + n;
+        const bool live = b < B && ulive;
+        const f32x4 hp = __builtin_bit_cast(f32x4, in.hp);      // (whole vector: a bit_cast of ONE element reads element 0)
+        f32x4 o, rg, zg, ng, qv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rg[i] = cl_sigmoid(in.gr[i] + a_r[i] + bias[0][i]);
+            zg[i] = cl_sigmoid(in.gz[i] + a_z[i] + bias[1][i]);
+            qv[i] = a_n[i] + bias[2][i];
+            ng[i] = cl_tanh(in.gn[i] + rg[i] * qv[i]);
+            o[i] = live ? ng[i] + zg[i] * (hp[i] - ng[i]) : 0.f;
+        }
+        if (sn + 1 < T) {
+            const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
+            if constexpr (BF) {
+                bf16x4 sh, sl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(o[i], a, c); sh[i] = a; sl[i] = c; }
+                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
+                if (fast) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                }
+            } else {
+                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
+                if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, AUX_SC1);
+            }
+        }
+        if (live) {
+            *reinterpret_cast<f32x4*>(p.y_ext + ((long long)(t + 1) * B + b) * ldy + dir * H + ju) = o;
+            if (p.saved) {
+                float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H + ju;
+                *reinterpret_cast<f32x4*>(sv) = rg;
+                *reinterpret_cast<f32x4*>(sv + H) = zg;
+                *reinterpret_cast<f32x4*>(sv + 2 * H) = ng;
+                *reinterpret_cast<f32x4*>(sv + 3 * H) = qv;
+            }
+        }
+    };
+    // the finished products of round itn for this wave's tile(s): own k-half (registers) + the partner's (LDS)
+    auto finish = [&](int itn, const EpiIn (&ein)[NTE], const f32x4 (&own)[NTE][3]) {
+#pragma unroll
+        for (int te = 0; te < NTE; ++te) {
+            f32x4 a_r = own[te][0], a_z = own[te][1], a_n = own[te][2];
+            if constexpr (KSPLIT == 2) {
+                const unsigned char* xr_ = xch + (itn & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
+                a_r += *reinterpret_cast<const f32x4*>(xr_);
+                a_z += *reinterpret_cast<const f32x4*>(xr_ + 1024);
+                a_n += *reinterpret_cast<const f32x4*>(xr_ + 2048);
+            }
+            epilogue(itn, te, ein[te], a_r, a_z, a_n);
+        }
+    };
+
+    EpiIn ein[NTE], ein_next[NTE];
+    f32x4 own[NTE][3];
+#pragma unroll
+    for (int te = 0; te < NTE; ++te) epi_load(it_begin, te, ein_next[te]);
+    for (int it = it_begin; it < it_end; ++it) {
+        // (1) the exchange rows of round it - 2 were stored during round it - 1 and drained before the last barrier
+        if (p.handoff && tid == 0 && it >= it_begin + 2) {
+            const int itp = it - 2;
+            const int sp = itp / NR, rp = itp - sp * NR;
+            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (2) gate math of the previous round
+        if (it > it_begin) finish(it - 1, ein, own);
+        // (3) requests
+#pragma unroll
+        for (int te = 0; te < NTE; ++te) ein[te] = ein_next[te];
+        if (it + 1 < it_end) {
+#pragma unroll
+            for (int te = 0; te < NTE; ++te) epi_load(it + 1, te, ein_next[te]);
+        }
         const int it2 = it + 2;
         const int s2 = it2 / NR, r2 = it2 - s2 * NR;
         const bool do_poll = p.handoff && wave == 0 && it2 < it_end && s2 > p.s_begin;
         unsigned fl = 0xffffffffu;
         if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f32x4 e_r[NTE], e_z[NTE], e_n[NTE];
-        u32x4 e_h[NTE];
-#pragma unroll
-        for (int te = 0; te < NTE; ++te) {
-            const int tsel = KSPLIT == 2 ? kh : te;
-            const int b = m_base + 32 * r + 16 * tsel + n;
-            const int bc = b < B ? b : B - 1;
-            const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
-            e_r[te] = *reinterpret_cast<const f32x4*>(gp);
-            e_z[te] = *reinterpret_cast<const f32x4*>(gp + H);
-            e_n[te] = *reinterpret_cast<const f32x4*>(gp + 2 * H);
-            // own previous state (fp32), written by this lane one step ago (or by the init kernel)
-            e_h[te] = __builtin_amdgcn_raw_buffer_load_b128(yr, (unsigned)((((long long)slot_prev * B + bc) * ldy + dir * H + juc) * 4), 0, AUX_SC1);
-        }
 
-        // (B) h_{t-1} W_hh^T for two trial tiles: D[row = unit 4kq + i][col = trial n]
+        // (4) h_{t-1} W_hh^T for two trial tiles: D[row = unit 4kq + i][col = trial n]; DMA pieces of the next round between the chunks
+        const bool has_next = it + 1 < it_end;
+        const unsigned char* src = dma_src(has_next ? it + 1 : it);
         f32x4 acc[2][3];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
@@ -298,112 +418,64 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
         if constexpr (BF) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
+                if (has_next) {
+#pragma unroll
+                    for (int i = c * PPW / 8; i < (c + 1) * PPW / 8; ++i) dma_piece(src, it + 1, i);
+                }
                 bf16x8 bh[2], bl[2];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    const unsigned char* rp = tb + ((tt * 16 + n) * 2) * RS + (kbase + 32 * c + 8 * kq) * 2;
+                    const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                     bh[tt] = *reinterpret_cast<const bf16x8*>(rp);
-                    bl[tt] = *reinterpret_cast<const bf16x8*>(rp + RS);
+                    bl[tt] = *reinterpret_cast<const bf16x8*>(rp + PS);
                 }
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
-                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g][c], bh[tt], acc[tt][g], 0, 0, 0);
-                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g][c], bl[tt], acc[tt][g], 0, 0, 0);
-                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g][c], bh[tt], acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[g][c], bh[tt], acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bl[tt], acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bh[tt], acc[tt][g], 0, 0, 0);
                     }
             }
         } else {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
+                if (has_next) {
+#pragma unroll
+                    for (int i = c * PPW / 16; i < (c + 1) * PPW / 16; ++i) dma_piece(src, it + 1, i);
+                }
                 f32x4 a4[2];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
-                    a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * RS + (kbase + 16 * c + 4 * kq) * 4);
+                    a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                         for (int g = 0; g < 3; ++g)
-                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][c][e], a4[tt][e], acc[tt][g], 0, 0, 0);
+                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.wf[g][c][e], a4[tt][e], acc[tt][g], 0, 0, 0);
             }
         }
 
-        // (C) swap partial sums with the other k-half, commit the staged operand, one barrier
+        // (5) hand the other tile's partial sums to the k-partner, keep this wave's own; drain; barrier
         if constexpr (KSPLIT == 2) {
             unsigned char* xw = xch + (it & 1) * (4 * 3 * 1024) + wave * (3 * 1024) + lane * 16;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(xw + g * 1024) = kh ? acc[0][g] : acc[1][g];
+            for (int g = 0; g < 3; ++g) {
+                *reinterpret_cast<f32x4*>(xw + g * 1024) = kh ? acc[0][g] : acc[1][g];
+                own[0][g] = kh ? acc[1][g] : acc[0][g];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { own[0][g] = acc[0][g]; own[NTE - 1][g] = acc[1][g]; }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed, its stores are complete
         if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)s2, p.CS, lane, fl, p.status);
-        if (has_next) stage_commit(it + 1, st);
         __syncthreads();
-        // every wave's exchange stores of the previous round were issued before the loads it has just committed: they are complete
-        if (p.handoff && tid == 0 && it > it_begin) {
-            const int itp = it - 1;
-            const int sp = itp / NR, rp = itp - sp * NR;
-            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-
-        // (D) gates + hidden update for this wave's trial tile(s)
-#pragma unroll
-        for (int te = 0; te < NTE; ++te) {
-            const int tsel = KSPLIT == 2 ? kh : te;
-            f32x4 a_r = tsel ? acc[1][0] : acc[0][0], a_z = tsel ? acc[1][1] : acc[0][1], a_n = tsel ? acc[1][2] : acc[0][2];
-            if constexpr (KSPLIT == 2) {
-                const unsigned char* xr_ = xch + (it & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
-                a_r += *reinterpret_cast<const f32x4*>(xr_);
-                a_z += *reinterpret_cast<const f32x4*>(xr_ + 1024);
-                a_n += *reinterpret_cast<const f32x4*>(xr_ + 2048);
-            }
-            const int b = m_base + 32 * r + 16 * tsel + n;
-            const bool live = b < B;
-            const f32x4 hp = __builtin_bit_cast(f32x4, e_h[te]);      // (whole vector: a bit_cast of ONE element reads element 0)
-            f32x4 o, rg, zg, ng, qv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rg[i] = cl_sigmoid(e_r[te][i] + a_r[i] + bias[0][i]);
-                zg[i] = cl_sigmoid(e_z[te][i] + a_z[i] + bias[1][i]);
-                qv[i] = a_n[i] + bias[2][i];
-                ng[i] = cl_tanh(e_n[te][i] + rg[i] * qv[i]);
-                o[i] = (ulive && live) ? ng[i] + zg[i] * (hp[i] - ng[i]) : 0.f;
-            }
-            // exchange first (write-through), so that the next round's operand loads are younger than these stores
-            if (s + 1 < T) {
-                const unsigned row = (unsigned)((((s + 1) & 1) * p.ndir + dir) * p.Bp + b);
-                if constexpr (BF) {
-                    bf16x4 sh, sl;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(o[i], a, c); sh[i] = a; sl[i] = c; }
-                    const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
-                    if (fast) {
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
-                    }
-                } else {
-                    const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
-                    if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, AUX_SC1);
-                }
-            }
-            if (live && ulive) {
-                *reinterpret_cast<f32x4*>(p.y_ext + ((long long)(t + 1) * B + b) * ldy + dir * H + ju) = o;
-                if (p.saved) {
-                    float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H + ju;
-                    *reinterpret_cast<f32x4*>(sv) = rg;
-                    *reinterpret_cast<f32x4*>(sv + H) = zg;
-                    *reinterpret_cast<f32x4*>(sv + 2 * H) = ng;
-                    *reinterpret_cast<f32x4*>(sv + 3 * H) = qv;
-                }
-            }
-        }
-        asm volatile("" ::: "memory");        // the exchange stores stay ahead of the next iteration's loads in program order
     }
+    if (it_end > it_begin) finish(it_end - 1, ein, own);        // (outputs of the launch's last round; nobody waits for its flag)
 }
 
 // h0 -> slots of y_ext and parity 0 of the exchange buffer (all Bp rows, all KP columns: pads are zero)
@@ -442,6 +514,8 @@ __global__ void gru_cluster_init_kernel(const float* __restrict__ h0, float* __r
 // W_hh^T: 16 units x 3 x 256 k per wave) and the gate gradients of the same units; the contraction runs
 // over all 3H gate-gradient columns, exchanged per step as three gate segments of KP columns.
 // Processing step ps = 0 .. T-1 handles s = T-1-ps (t = s forward, T-1-s reverse); ps = T is the dh0 pass.
+// Sub-iteration q = (ps, round r, gate segment g) contracts one 64-KiB operand image; the gate gradients of a round
+// are computed one sub-iteration after its last segment (same schedule as the forward kernel's rounds).
 // ------------------------------------------------------------------------------------------------------
 struct ClBwd {
     const float* dy;
@@ -465,10 +539,11 @@ struct ClBwd {
 template <int KSPLIT, bool BF>
 __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
     using Cf = ClCfg<KSPLIT, BF, 3>;
-    constexpr int KP = Cf::KP, RS = Cf::RS, PIECES = Cf::PIECES, PPR = Cf::PPR, TILE = Cf::TILE_BYTES;
+    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 4;
     constexpr int NTE = KSPLIT == 2 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xch = smem + 2 * TILE;
+    const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -493,59 +568,14 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
     __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
 
-    // ---- resident weights: A rows = units j0 + n, k = gate segment g, kbase + ... ----
-    bf16x8 wh[BF ? 3 : 1][BF ? 8 : 1], wl[BF ? 3 : 1][BF ? 8 : 1];
-    float wf[BF ? 1 : 3][BF ? 1 : 16][4];
+    ClWeights<BF> w;
     {
         const int jr = j0 + n;
         const bool rlive = jr < H;
-        const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            if constexpr (BF) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int k = kbase + 32 * c + 8 * kq;
-                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                    if (rlive && k + 3 < H) v0 = *reinterpret_cast<const f32x4*>(wrow + g * H + k);
-                    if (rlive && k + 7 < H) v1 = *reinterpret_cast<const f32x4*>(wrow + g * H + k + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        __bf16 a, b;
-                        bf_split(v0[e], a, b); wh[g][c][e] = a; wl[g][c][e] = b;
-                        bf_split(v1[e], a, b); wh[g][c][4 + e] = a; wl[g][c][4 + e] = b;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int k = kbase + 16 * c + 4 * kq;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (rlive && k + 3 < H) v = *reinterpret_cast<const f32x4*>(wrow + g * H + k);
-                    wf[g][c][0] = v[0]; wf[g][c][1] = v[1]; wf[g][c][2] = v[2]; wf[g][c][3] = v[3];
-                }
-            }
-        }
+        const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H + kbase;
+        const float* const seg[3] = {wrow, wrow + H, wrow + 2 * H};
+        w.load(seg, rlive, kq, H - kbase, WT);
     }
-
-    // sub-iteration q = ps * NQ + r * 3 + g reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1)
-    auto stage_issue = [&](int qn, u32x4 (&st)[PIECES]) {
-        const int psn = qn / NQ, rem = qn - psn * NQ;
-        const unsigned chunk = (unsigned)(((((psn - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + rem / 3) * 3 + rem % 3);
-        const unsigned base = chunk * (unsigned)Cf::CHUNK_BYTES;
-#pragma unroll
-        for (int e = 0; e < PIECES; ++e)
-            st[e] = __builtin_amdgcn_raw_buffer_load_b128(xr, base + (unsigned)(tid + 256 * e) * 16u, 0, AUX_SC1);
-    };
-    auto stage_commit = [&](int qn, const u32x4 (&st)[PIECES]) {
-        unsigned char* dst = smem + (qn & 1) * TILE;
-#pragma unroll
-        for (int e = 0; e < PIECES; ++e) {
-            const int i = tid + 256 * e;
-            *reinterpret_cast<u32x4*>(dst + (i / PPR) * RS + (i % PPR) * 16) = st[e];
-        }
-    };
-
 #ifdef XPS_CL_STAMP
     rt[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -553,6 +583,19 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
 #ifdef XPS_CL_STAMP
     rt[2] = __builtin_amdgcn_s_memrealtime();
 #endif
+
+    // sub-iteration q = ps * NQ + r * 3 + g reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1)
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+    auto dma_src = [&](int qn) -> const unsigned char* {
+        const int psn = qn / NQ, rem = qn - psn * NQ;
+        const size_t chunk = (size_t)(((((psn - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + rem / 3) * 3 + rem % 3);
+        return xb + chunk * Cf::CHUNK_BYTES + (size_t)(wave * PPW) * 1024 + lane * 16;
+    };
+    auto dma_piece = [&](const unsigned char* src, int qn, int i) {
+        const unsigned dst = lds0 + (unsigned)((qn & 1) * TILE) +
+                             (unsigned)(Cf::PPT == 2 ? ((wave * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (wave * PPW + i) * TS);
+        cl_dma_piece(src + i * 1024, dst);
+    };
 
     struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
     auto epi_load = [&](int ps, int r, int te, EpiIn& in) {
@@ -655,32 +698,44 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
         // drain, then publish every round of step 0 at once
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (p.handoff && wave == 0 && lane < NR)
-            __hip_atomic_store(myflags + lane * 16 + cm.member, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int r = 64; p.handoff && wave == 0 && r < NR; r += 64)
+        for (int r = 0; p.handoff && wave == 0 && r < NR; r += 64)
             if (r + lane < NR) __hip_atomic_store(myflags + (r + lane) * 16 + cm.member, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-
 #ifdef XPS_CL_STAMP
     rt[3] = __builtin_amdgcn_s_memrealtime();
 #endif
+
     const int q_begin = ps0 * NQ, q_end = p.ps_end * NQ;
     if (p.handoff && wave == 0) {
         // the first two sub-iterations (round 0, segments 0 and 1) are loaded without a look-ahead poll
-        unsigned f0 = 0;
+        unsigned f0 = 0xffffffffu;
         if (lane < p.CS) f0 = __hip_atomic_load(myflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cl_wait(myflags, (unsigned)ps0, p.CS, lane, lane < p.CS ? f0 : 0xffffffffu, p.status);
+        cl_wait(myflags, (unsigned)ps0, p.CS, lane, f0, p.status);
     }
     __syncthreads();
     {
-        u32x4 st0[PIECES];
-        stage_issue(q_begin, st0);
-        stage_commit(q_begin, st0);
+        const unsigned char* src = dma_src(q_begin);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(src, q_begin, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
     f32x4 acc[2];
+    f32x4 own[NTE];                  // finished k-half products of the round whose gate math is pending
     EpiIn ein[NTE];
+    int pend_ps = -1, pend_r = 0;    // round whose gate math runs in the next sub-iteration
+    auto finish = [&](int qlast) {   // qlast: the g == 2 sub-iteration of the pending round
+#pragma unroll
+        for (int te = 0; te < NTE; ++te) {
+            f32x4 a = own[te];
+            if constexpr (KSPLIT == 2) {
+                const unsigned char* xr_ = xch + ((qlast / 3) & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
+                a += *reinterpret_cast<const f32x4*>(xr_);
+            }
+            epilogue(pend_ps, pend_r, te, ein[te], a);
+        }
+    };
 #ifdef XPS_CL_STAMP
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, a_issue = 0, a_mfma = 0, a_poll = 0, a_commit = 0, a_bar = 0, a_epi = 0, c_begin = 0, c_end = 0;
     CL_STAMP(c_begin)
@@ -690,9 +745,21 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
         const int ps = q / NQ, rem = q - ps * NQ;
         const int r = rem / 3, g = rem - 3 * r;
         CL_STAMP(c0)
-        u32x4 st[PIECES];
-        const bool has_next = q + 1 < q_end;
-        if (has_next) stage_issue(q + 1, st);
+        // (1) the gate gradients stored during sub-iteration q - 1 (gate math of the round that ended at q - 2) were drained
+        //     before the last barrier
+        if (p.handoff && tid == 0 && g == 1 && q - 2 >= q_begin) {
+            const int qp = q - 2;
+            const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
+            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (2) gate math of the round that finished its contraction in the previous sub-iteration
+        if (g == 0 && pend_ps >= 0) { finish(q - 1); pend_ps = -1; }
+        CL_STAMP(c1)
+        // (3) requests: inputs of this round's gate math, flags of the round after next
+        if (g == 1) {
+#pragma unroll
+            for (int te = 0; te < NTE; ++te) epi_load(ps, r, te, ein[te]);
+        }
         const int q2 = q + 2;
         const int ps2 = q2 / NQ, rem2 = q2 - ps2 * NQ;
         const int r2 = rem2 / 3;
@@ -703,87 +770,79 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
             acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[1] = acc[0];
         }
-        if (g == 1) {
-#pragma unroll
-            for (int te = 0; te < NTE; ++te) epi_load(ps, r, te, ein[te]);
-        }
 
-        CL_STAMP(c1)
+        // (4) contraction of segment g, DMA pieces of the next sub-iteration between the chunks
+        const bool has_next = q + 1 < q_end;
+        const unsigned char* src = dma_src(has_next ? q + 1 : q);
         const unsigned char* tb = smem + (q & 1) * TILE;
-        // the gate segment is a runtime value: select the register block with a uniform branch per segment
         auto contract = [&](auto G) {
             constexpr int gg = decltype(G)::value;
             if constexpr (BF) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
+                    if (has_next) {
+#pragma unroll
+                        for (int i = c * PPW / 8; i < (c + 1) * PPW / 8; ++i) dma_piece(src, q + 1, i);
+                    }
                     bf16x8 bh[2], bl[2];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        const unsigned char* rp = tb + ((tt * 16 + n) * 2) * RS + (kbase + 32 * c + 8 * kq) * 2;
+                        const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                         bh[tt] = *reinterpret_cast<const bf16x8*>(rp);
-                        bl[tt] = *reinterpret_cast<const bf16x8*>(rp + RS);
+                        bl[tt] = *reinterpret_cast<const bf16x8*>(rp + PS);
                     }
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[gg][c], bh[tt], acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[gg][c], bl[tt], acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[gg][c], bh[tt], acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[gg][c], bh[tt], acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bl[tt], acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bh[tt], acc[tt], 0, 0, 0);
                     }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
+                    if (has_next) {
+#pragma unroll
+                        for (int i = c * PPW / 16; i < (c + 1) * PPW / 16; ++i) dma_piece(src, q + 1, i);
+                    }
                     f32x4 a4[2];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt)
-                        a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * RS + (kbase + 16 * c + 4 * kq) * 4);
+                        a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int tt = 0; tt < 2; ++tt)
-                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gg][c][e], a4[tt][e], acc[tt], 0, 0, 0);
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.wf[gg][c][e], a4[tt][e], acc[tt], 0, 0, 0);
                 }
             }
         };
         if (g == 0) contract(std::integral_constant<int, 0>{});
         else if (g == 1) contract(std::integral_constant<int, 1>{});
         else contract(std::integral_constant<int, 2>{});
+        CL_STAMP(c2)
 
-        if constexpr (KSPLIT == 2) {
-            if (g == 2) {
+        // (5) last segment: hand the other tile's partial sums to the k-partner; drain; barrier
+        if (g == 2) {
+            if constexpr (KSPLIT == 2) {
                 unsigned char* xw = xch + ((q / 3) & 1) * (4 * 3 * 1024) + wave * (3 * 1024) + lane * 16;
                 *reinterpret_cast<f32x4*>(xw) = kh ? acc[0] : acc[1];
+                own[0] = kh ? acc[1] : acc[0];
+            } else {
+                own[0] = acc[0]; own[NTE - 1] = acc[1];
             }
+            pend_ps = ps; pend_r = r;
         }
-        CL_STAMP(c2)
-        if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed, its stores are complete
         CL_STAMP(c3)
-        if (has_next) stage_commit(q + 1, st);
+        if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
         CL_STAMP(c4)
         __syncthreads();
         CL_STAMP(c5)
-        // publish the round whose gate gradients were stored at the end of the previous sub-iteration
-        if (p.handoff && tid == 0 && g == 0 && q > q_begin) {
-            const int qp = q - 1;
-            const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
-            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (g == 2) {
-#pragma unroll
-            for (int te = 0; te < NTE; ++te) {
-                const int tsel = KSPLIT == 2 ? kh : te;
-                f32x4 a = tsel ? acc[1] : acc[0];
-                if constexpr (KSPLIT == 2) {
-                    const unsigned char* xr_ = xch + ((q / 3) & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
-                    a += *reinterpret_cast<const f32x4*>(xr_);
-                }
-                epilogue(ps, r, te, ein[te], a);
-            }
-            asm volatile("" ::: "memory");
-        }
         CL_STAMP(c6)
-        CL_ACC(a_issue, c0, c1) CL_ACC(a_mfma, c1, c2) CL_ACC(a_poll, c2, c3) CL_ACC(a_commit, c3, c4) CL_ACC(a_bar, c4, c5) CL_ACC(a_epi, c5, c6)
+        CL_ACC(a_epi, c0, c1) CL_ACC(a_issue, c1, c1) CL_ACC(a_mfma, c1, c2) CL_ACC(a_commit, c2, c3) CL_ACC(a_poll, c3, c4) CL_ACC(a_bar, c4, c5)
     }
+    if (pend_ps >= 0) finish(q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
 #ifdef XPS_CL_STAMP
     CL_STAMP(c_end)
     if (lane == 0) {

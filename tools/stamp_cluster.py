@@ -28,11 +28,11 @@ for mode in sys.argv[1:] or ['persistent']:
     print(mode, 'wall clock (us since the first wave entered; median / max over waves): entry %.1f/%.1f  weights done %.1f/%.1f  xcd check done %.1f/%.1f  pre-phase done %.1f/%.1f  loop begin %.1f/%.1f  loop end %.1f/%.1f' % tuple(
         v for i in range(6) for v in (np.median(rt[:, i] - t0) / 100, (rt[:, i] - t0).max() / 100)))
     nq = (T - 1) * 24 if mode == 'persistent' else 24
-    names = ['issue', 'mfma', 'poll', 'commit(wait loads)', 'barrier', 'epilogue']
+    names = ['(unused)', 'requests + contraction + DMA issue', 'poll check', 'drain: vmcnt(0)', 'barrier', 'publish + gate math of previous round']
     print(mode, 'per sub-iteration cycles (median over waves; wave 0 / others):')
     w0 = raw[0::4]; wo = np.concatenate([raw[1::4], raw[2::4], raw[3::4]])
     for i, nme in enumerate(names):
-        print(f'   {nme:20s} {np.median(w0[:, i]) / nq:9.0f} {np.median(wo[:, i]) / nq:9.0f}')
+        print(f'   {nme:44s} {np.median(w0[:, i]) / nq:9.0f} {np.median(wo[:, i]) / nq:9.0f}')
     print('   loop total cycles median', np.median(raw[:, 7] - raw[:, 6]), ' per sub-iteration', np.median(raw[:, 7] - raw[:, 6]) / nq)
     dur = raw[:, 7] - raw[:, 6]
     print('   loop cycles: min %.0f p50 %.0f p90 %.0f max %.0f' % (dur.min(), np.median(dur), np.percentile(dur, 90), dur.max()))
