@@ -56,8 +56,10 @@ struct ClCfg {
     static constexpr int TS = TRIAL_BYTES + 32;              // trial stride in LDS (2080 or 1056)
     static constexpr int PS = BF ? (PPT == 2 ? 1040 : 512) : 0;            // plane stride (bf16): KP = 512: its own padded piece
     static constexpr int TILE_BYTES = 32 * TS;
-    static constexpr int XCH_BYTES = KSPLIT == 2 ? 2 * 4 * 3 * 1024 : 0;   // partial-sum swap, double buffered
-    static constexpr int LDS_BYTES = 2 * TILE_BYTES + XCH_BYTES;
+    // products handed from the contraction waves to the gate-math waves: [wave 4][tile 2][gate 3] x 1 KiB (forward, one buffer +
+    // a consumed word per gate-math wave) or [parity 2][wave 4][tile 2] x 1 KiB (backward)
+    static constexpr int XACC_BYTES = KSEG == 1 ? 4 * 2 * 3 * 1024 : 2 * 4 * 2 * 1024;
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES + XACC_BYTES + 64;
     static constexpr int KSEGS = KSEG;                       // gate segments of the contraction (forward 1, backward 3)
     // LDS offset of DMA piece j inside a round image
     __host__ __device__ static constexpr int piece_off(int j) {
@@ -110,8 +112,8 @@ __device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int
 // its XCC id, one wave collects the CS ids.  Same XCD: the members share an L2, so exchange stores may stay write-back
 // (plain) and the sc1 loads (which bypass L1 only) hit that L2 instead of going to the memory side.  Otherwise every
 // exchange store is write-through (sc1).  All members read the same table, so the whole cluster takes the same decision.
-__device__ inline bool cl_same_xcd(unsigned* tab, int member, int cs, int lane, int wave, unsigned* status, unsigned* lds_word) {
-    if (wave == 0) {
+__device__ inline bool cl_same_xcd(unsigned* tab, int member, int cs, int lane, bool leader, unsigned* status, unsigned* lds_word) {
+    if (leader) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
         id = (id & 15u) + 1u;
@@ -203,6 +205,8 @@ struct ClWeights {
                     wf[g][c][0] = v[0]; wf[g][c][1] = v[1]; wf[g][c][2] = v[2]; wf[g][c][3] = v[3];
                 }
             }
+            // one segment's loads in flight at a time: the fp32 temporaries of all three would not fit beside the fragments
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 };
@@ -225,89 +229,148 @@ struct ClFwd {
     int s_begin, s_end, handoff;
 };
 
-// Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster).  Between two barriers a wave
-//   (1) publishes the round whose exchange stores were drained before the previous barrier,
-//   (2) runs the gate math of round it - 1 (its own k-half of the products kept in registers, the other half read from LDS),
-//       stores the outputs and the exchange rows,
-//   (3) requests the gate inputs of round it and the flags of round it + 2,
-//   (4) contracts round it (buffer it & 1) while its LDS-DMA pieces of round it + 1 stream into the other buffer,
-//   (5) waits for everything it issued (vmcnt(0)): DMA landed, stores complete; then the barrier.
+// 512 threads: waves 0-3 CONTRACT (resident W_hh fragments, LDS operand reads, MFMA, nothing else), waves 4-7 do everything
+// else (LDS-DMA of the next round's operand, gate math of the previous round, global loads / stores, flags): every SIMD holds
+// one wave of each kind, so the matrix pipe never waits for a vector-memory issue slot or for the gate math.
+// Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster); between two barriers
+//   contraction wave (ut, kh): h_{t-1} W_hh^T of two trial tiles over its k-half -> xacc (once the gate-math waves have taken
+//                     the previous round's products out: one LDS word per gate-math wave, no second barrier);
+//   gate-math wave h: publishes round it - 2 (its exchange rows were drained before the last barrier), issues its DMA pieces
+//                     of round it + 1 into the other buffer, finishes round it - 1 (sums the two k-halves from xacc, gates,
+//                     hidden update, output + exchange stores), requests the gate inputs of round it + 1 and the flags of
+//                     round it + 2, then drains (vmcnt(0): DMA landed, stores complete) before the barrier.
 template <int KSPLIT, bool BF>
-__global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
+__global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     using Cf = ClCfg<KSPLIT, BF, 1>;
     constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 4;
-    constexpr int NTE = KSPLIT == 2 ? 1 : 2;          // trial tiles whose gate math this wave runs per round
+    constexpr int NTE = KSPLIT == 2 ? 1 : 2;          // trial tiles whose gate math one wave runs per round
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xch = smem + 2 * TILE;
+    unsigned char* xacc = smem + 2 * TILE;
+    unsigned* consumed = reinterpret_cast<unsigned*>(xacc + Cf::XACC_BYTES);      // [4] rounds taken out of xacc, per gate-math wave
     const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool contract_role = wave < 4;
+    const int cw = wave & 3;
     const int n = lane & 15, kq = lane >> 4;
-    const int ut = wave / KSPLIT, kh = wave % KSPLIT;
     const ClMap cm = cl_map(p.CS);
     const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
     const int T = p.T, B = p.B, H = p.H, NR = p.NR;
-    const int j0 = cm.member * Cf::U + ut * 16;        // first unit of this wave's tile
+    const int ldy = p.ndir * H;
+    const int m_base = blk * p.Mc;
+    const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
+    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
+    if (tid < 4) consumed[tid] = 0u;
+
+    // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
+
+    // this wave's share of round itn's operand (gate-math waves): PPW pieces -> buffer itn & 1
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+    auto dma_round = [&](int itn) {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        const unsigned char* src = xb + (size_t)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (KP * 4) + (size_t)(cw * PPW) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            // piece index cw * PPW + i; PPW is even, so the plane / half of a piece is that of i
+            const unsigned dst = lds0 + (unsigned)((itn & 1) * TILE) +
+                                 (unsigned)(Cf::PPT == 2 ? ((cw * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (cw * PPW + i) * TS);
+            cl_dma_piece(src + i * 1024, dst);
+        }
+    };
+    if (!contract_role) {
+        dma_round(it_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    if (contract_role) {
+        // ---------------- contraction waves ----------------
+        const int ut = cw / KSPLIT, kh = cw % KSPLIT;
+        const int j0 = cm.member * Cf::U + ut * 16;
+        const int kbase = kh * 256;
+        const float* __restrict__ W = p.w_hh[dir];
+        ClWeights<BF> w;
+        {
+            const int jr = j0 + n;
+            const bool rlive = jr < H;
+            const int jrc = rlive ? jr : 0;
+            const float* const seg[3] = {W + (long long)(0 * H + jrc) * H + kbase, W + (long long)(1 * H + jrc) * H + kbase,
+                                         W + (long long)(2 * H + jrc) * H + kbase};
+            w.load(seg, rlive, kq, H - kbase, W);
+        }
+        // gate-math waves that read this wave's products: (KSPLIT == 2) waves 2 ut and 2 ut + 1; (KSPLIT == 1) wave cw
+        const int c0 = KSPLIT == 2 ? (cw & ~1) : cw, c1 = KSPLIT == 2 ? (cw | 1) : cw;
+        for (int it = it_begin; it < it_end; ++it) {
+            const unsigned char* tb = smem + (it & 1) * TILE;
+            f32x4 acc[2][3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (BF) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[g][c], bh, acc[tt][g], 0, 0, 0);
+                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bl, acc[tt][g], 0, 0, 0);
+                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bh, acc[tt][g], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int g = 0; g < 3; ++g)
+                                acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.wf[g][c][e], a4[e], acc[tt][g], 0, 0, 0);
+                    }
+                }
+            }
+            // the previous round's products must have been taken out of xacc (they were, two thousand cycles ago: one look)
+            if (it > it_begin) {
+                const unsigned want = (unsigned)(it - it_begin);
+                while (__hip_atomic_load(consumed + c0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
+                       __hip_atomic_load(consumed + c1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    *reinterpret_cast<f32x4*>(xacc + ((cw * 2 + tt) * 3 + g) * 1024 + lane * 16) = acc[tt][g];
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- gate-math / memory waves ----------------
+    const int hut = KSPLIT == 2 ? (cw >> 1) : cw;      // unit tile of this wave's gate math
+    const int j0 = cm.member * Cf::U + hut * 16;
     const int ju = j0 + 4 * kq;                        // this lane's four units
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
-    const int kbase = kh * 256;
-    const int ldy = p.ndir * H;
-    const int m_base = blk * p.Mc;
-    const float* __restrict__ W = p.w_hh[dir];
     const float* __restrict__ gi = p.gi + (long long)dir * T * B * 3 * H;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y_ext, 0, (unsigned)((long long)(T + 2) * B * ldy * 4), RSRC_FLAGS);
-    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
-
-    ClWeights<BF> w;
-    {
-        const int jr = j0 + n;
-        const bool rlive = jr < H;
-        const int jrc = rlive ? jr : 0;
-        const float* const seg[3] = {W + (long long)(0 * H + jrc) * H + kbase, W + (long long)(1 * H + jrc) * H + kbase,
-                                     W + (long long)(2 * H + jrc) * H + kbase};
-        w.load(seg, rlive, kq, H - kbase, W);
-    }
     f32x4 bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         bias[g] = *reinterpret_cast<const f32x4*>(p.b_hh[dir] + g * H + juc);
         if (!ulive) bias[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-
-    // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
-    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave, p.status, reinterpret_cast<unsigned*>(smem));
-
-    // this wave's share of round itn's operand: PPW pieces -> buffer itn & 1
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
-    auto dma_src = [&](int itn) -> const unsigned char* {
-        const int sn = itn / NR, rn = itn - sn * NR;
-        return xb + (size_t)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (KP * 4) + (size_t)(wave * PPW) * 1024 + lane * 16;
-    };
-    auto dma_piece = [&](const unsigned char* src, int itn, int i) {      // i = 0 .. PPW - 1 (compile time at every call site)
-        // the piece index is wave * PPW + i; PPW is even, so the plane / half of a piece is that of i
-        const unsigned dst = lds0 + (unsigned)((itn & 1) * TILE) +
-                             (unsigned)(Cf::PPT == 2 ? ((wave * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (wave * PPW + i) * TS);
-        cl_dma_piece(src + i * 1024, dst);
-    };
-
-    const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
-    {
-        const unsigned char* src = dma_src(it_begin);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_piece(src, it_begin, i);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-    // gate inputs of a round (requested one round before they are used)
     struct EpiIn { f32x4 gr, gz, gn; u32x4 hp; };
     auto epi_load = [&](int itn, int te, EpiIn& in) {
         const int sn = itn / NR, rn = itn - sn * NR;
         const int t = (dir == 0) ? sn : T - 1 - sn;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int tsel = KSPLIT == 2 ? kh : te;
+        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
         const int b = m_base + 32 * rn + 16 * tsel + n;
         const int bc = b < B ? b : B - 1;
         const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
@@ -321,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
     auto epilogue = [&](int itn, int te, const EpiIn& in, f32x4 a_r, f32x4 a_z, f32x4 a_n) {
         const int sn = itn / NR, rn = itn - sn * NR;
         const int t = (dir == 0) ? sn : T - 1 - sn;
-        const int tsel = KSPLIT == 2 ? kh : te;
+        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
         const int b = m_base + 32 * rn + 16 * tsel + n;
         const bool live = b < B && ulive;
         const f32x4 hp = __builtin_bit_cast(f32x4, in.hp);      // (whole vector: a bit_cast of ONE element reads element 0)
@@ -365,35 +428,43 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
             }
         }
     };
-    // the finished products of round itn for this wave's tile(s): own k-half (registers) + the partner's (LDS)
-    auto finish = [&](int itn, const EpiIn (&ein)[NTE], const f32x4 (&own)[NTE][3]) {
+    // products of the finished round for this wave's tile(s): k-low half + k-high half (KSPLIT == 2), taken out of xacc
+    f32x4 prod[NTE][3];
+    auto take_products = [&](int rounds_done) {
 #pragma unroll
         for (int te = 0; te < NTE; ++te) {
-            f32x4 a_r = own[te][0], a_z = own[te][1], a_n = own[te][2];
-            if constexpr (KSPLIT == 2) {
-                const unsigned char* xr_ = xch + (itn & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
-                a_r += *reinterpret_cast<const f32x4*>(xr_);
-                a_z += *reinterpret_cast<const f32x4*>(xr_ + 1024);
-                a_n += *reinterpret_cast<const f32x4*>(xr_ + 2048);
+            const int tsel = KSPLIT == 2 ? (cw & 1) : te;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                if constexpr (KSPLIT == 2) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut) * 2 + tsel) * 3 + g) * 1024 + lane * 16);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut + 1) * 2 + tsel) * 3 + g) * 1024 + lane * 16);
+                    prod[te][g] = lo + hi;
+                } else {
+                    prod[te][g] = *reinterpret_cast<const f32x4*>(xacc + ((cw * 2 + tsel) * 3 + g) * 1024 + lane * 16);
+                }
             }
-            epilogue(itn, te, ein[te], a_r, a_z, a_n);
         }
+        // the reads above must have returned before the contraction waves may overwrite xacc
+        if (lane == 0) __hip_atomic_store(consumed + cw, (unsigned)rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     EpiIn ein[NTE], ein_next[NTE];
-    f32x4 own[NTE][3];
 #pragma unroll
     for (int te = 0; te < NTE; ++te) epi_load(it_begin, te, ein_next[te]);
     for (int it = it_begin; it < it_end; ++it) {
-        // (1) the exchange rows of round it - 2 were stored during round it - 1 and drained before the last barrier
-        if (p.handoff && tid == 0 && it >= it_begin + 2) {
+        // the exchange rows of round it - 2 were stored during round it - 1 and drained before the last barrier
+        if (p.handoff && wave == 4 && lane == 0 && it >= it_begin + 2) {
             const int itp = it - 2;
             const int sp = itp / NR, rp = itp - sp * NR;
             __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // (2) gate math of the previous round
-        if (it > it_begin) finish(it - 1, ein, own);
-        // (3) requests
+        if (it + 1 < it_end) dma_round(it + 1);
+        if (it > it_begin) {
+            take_products(it - it_begin);
+#pragma unroll
+            for (int te = 0; te < NTE; ++te) epilogue(it - 1, te, ein[te], prod[te][0], prod[te][1], prod[te][2]);
+        }
 #pragma unroll
         for (int te = 0; te < NTE; ++te) ein[te] = ein_next[te];
         if (it + 1 < it_end) {
@@ -402,80 +473,18 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_fwd_kernel(ClFwd p) {
         }
         const int it2 = it + 2;
         const int s2 = it2 / NR, r2 = it2 - s2 * NR;
-        const bool do_poll = p.handoff && wave == 0 && it2 < it_end && s2 > p.s_begin;
+        const bool do_poll = p.handoff && wave == 4 && it2 < it_end && s2 > p.s_begin;
         unsigned fl = 0xffffffffu;
         if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        // (4) h_{t-1} W_hh^T for two trial tiles: D[row = unit 4kq + i][col = trial n]; DMA pieces of the next round between the chunks
-        const bool has_next = it + 1 < it_end;
-        const unsigned char* src = dma_src(has_next ? it + 1 : it);
-        f32x4 acc[2][3];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const unsigned char* tb = smem + (it & 1) * TILE;
-        if constexpr (BF) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (has_next) {
-#pragma unroll
-                    for (int i = c * PPW / 8; i < (c + 1) * PPW / 8; ++i) dma_piece(src, it + 1, i);
-                }
-                bf16x8 bh[2], bl[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
-                    bh[tt] = *reinterpret_cast<const bf16x8*>(rp);
-                    bl[tt] = *reinterpret_cast<const bf16x8*>(rp + PS);
-                }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[g][c], bh[tt], acc[tt][g], 0, 0, 0);
-                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bl[tt], acc[tt][g], 0, 0, 0);
-                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bh[tt], acc[tt][g], 0, 0, 0);
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if (has_next) {
-#pragma unroll
-                    for (int i = c * PPW / 16; i < (c + 1) * PPW / 16; ++i) dma_piece(src, it + 1, i);
-                }
-                f32x4 a4[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-                    a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                        for (int g = 0; g < 3; ++g)
-                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.wf[g][c][e], a4[tt][e], acc[tt][g], 0, 0, 0);
-            }
-        }
-
-        // (5) hand the other tile's partial sums to the k-partner, keep this wave's own; drain; barrier
-        if constexpr (KSPLIT == 2) {
-            unsigned char* xw = xch + (it & 1) * (4 * 3 * 1024) + wave * (3 * 1024) + lane * 16;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                *reinterpret_cast<f32x4*>(xw + g * 1024) = kh ? acc[0][g] : acc[1][g];
-                own[0][g] = kh ? acc[1][g] : acc[0][g];
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) { own[0][g] = acc[0][g]; own[NTE - 1][g] = acc[1][g]; }
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed, its stores are complete
         if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)s2, p.CS, lane, fl, p.status);
         __syncthreads();
     }
-    if (it_end > it_begin) finish(it_end - 1, ein, own);        // (outputs of the launch's last round; nobody waits for its flag)
+    if (it_end > it_begin) {                                    // (outputs of the launch's last round; nobody waits for its flag)
+        take_products(it_end - it_begin);
+#pragma unroll
+        for (int te = 0; te < NTE; ++te) epilogue(it_end - 1, te, ein[te], prod[te][0], prod[te][1], prod[te][2]);
+    }
 }
 
 // h0 -> slots of y_ext and parity 0 of the exchange buffer (all Bp rows, all KP columns: pads are zero)
@@ -537,64 +546,47 @@ struct ClBwd {
 };
 
 template <int KSPLIT, bool BF>
-__global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
+__global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     using Cf = ClCfg<KSPLIT, BF, 3>;
     constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 4;
     constexpr int NTE = KSPLIT == 2 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xch = smem + 2 * TILE;
+    unsigned char* xacc = smem + 2 * TILE;              // [round parity 2][contraction wave 4][tile 2] x 1 KiB
     const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool contract_role = wave < 4;
+    const int cw = wave & 3;
     const int n = lane & 15, kq = lane >> 4;
-    const int ut = wave / KSPLIT, kh = wave % KSPLIT;
     const ClMap cm = cl_map(p.CS);
     const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
     const int T = p.T, B = p.B, H = p.H, NR = p.NR;
-    const int j0 = cm.member * Cf::U + ut * 16;
-    const int ju = j0 + 4 * kq;
-    const bool ulive = ju < H;
-    const int juc = ulive ? ju : 0;
-    const int kbase = kh * 256;
     const int ldy = p.ndir * H;
     const int m_base = blk * p.Mc;
     const int NQ = 3 * NR;                              // sub-iterations (round, gate segment) per processing step
-#ifdef XPS_CL_STAMP
-    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
-    rt[0] = __builtin_amdgcn_s_memrealtime();
-#endif
-    const float* __restrict__ WT = p.w_hh_t[dir];
+    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
+
+    // gate-math waves: unit tile, units, buffers
+    const int hut = KSPLIT == 2 ? (cw >> 1) : cw;
+    const int ju = cm.member * Cf::U + hut * 16 + 4 * kq;
+    const bool ulive = ju < H;
+    const int juc = ulive ? ju : 0;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
-    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
-
-    ClWeights<BF> w;
-    {
-        const int jr = j0 + n;
-        const bool rlive = jr < H;
-        const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H + kbase;
-        const float* const seg[3] = {wrow, wrow + H, wrow + 2 * H};
-        w.load(seg, rlive, kq, H - kbase, WT);
-    }
-#ifdef XPS_CL_STAMP
-    rt[1] = __builtin_amdgcn_s_memrealtime();
-#endif
-    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave, p.status, reinterpret_cast<unsigned*>(smem));
-#ifdef XPS_CL_STAMP
-    rt[2] = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // sub-iteration q = ps * NQ + r * 3 + g reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1)
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
-    auto dma_src = [&](int qn) -> const unsigned char* {
+    auto dma_sub = [&](int qn) {
         const int psn = qn / NQ, rem = qn - psn * NQ;
         const size_t chunk = (size_t)(((((psn - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + rem / 3) * 3 + rem % 3);
-        return xb + chunk * Cf::CHUNK_BYTES + (size_t)(wave * PPW) * 1024 + lane * 16;
-    };
-    auto dma_piece = [&](const unsigned char* src, int qn, int i) {
-        const unsigned dst = lds0 + (unsigned)((qn & 1) * TILE) +
-                             (unsigned)(Cf::PPT == 2 ? ((wave * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (wave * PPW + i) * TS);
-        cl_dma_piece(src + i * 1024, dst);
+        const unsigned char* src = xb + chunk * Cf::CHUNK_BYTES + (size_t)(cw * PPW) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const unsigned dst = lds0 + (unsigned)((qn & 1) * TILE) +
+                                 (unsigned)(Cf::PPT == 2 ? ((cw * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (cw * PPW + i) * TS);
+            cl_dma_piece(src + i * 1024, dst);
+        }
     };
 
     struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
@@ -602,7 +594,7 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int tsel = KSPLIT == 2 ? kh : te;
+        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
         const int b = m_base + 32 * r + 16 * tsel + n;
         const int bc = b < B ? b : B - 1;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -625,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
     auto epilogue = [&](int ps, int r, int te, const EpiIn& in, const f32x4& acc) {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
-        const int tsel = KSPLIT == 2 ? kh : te;
+        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
         const int b = m_base + 32 * r + 16 * tsel + n;
         const bool live = b < B && ulive;
         f32x4 carry = __builtin_bit_cast(f32x4, in.keep);             // (whole vector: a bit_cast of ONE element reads element 0)
@@ -684,13 +676,15 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
 
     int ps0 = p.ps_begin;
     if (ps0 == 0) {
-        // first processing step: no contraction, the running gradient starts from dhn (or zero)
-        for (int r = 0; r < NR; ++r) {
+        // first processing step: no contraction, the running gradient starts from dhn (or zero); gate-math waves only
+        if (!contract_role) {
+            for (int r = 0; r < NR; ++r) {
 #pragma unroll
-            for (int te = 0; te < NTE; ++te) {
-                EpiIn in;
-                epi_load(0, r, te, in);
-                epilogue(0, r, te, in, (f32x4){0.f, 0.f, 0.f, 0.f});
+                for (int te = 0; te < NTE; ++te) {
+                    EpiIn in;
+                    epi_load(0, r, te, in);
+                    epilogue(0, r, te, in, (f32x4){0.f, 0.f, 0.f, 0.f});
+                }
             }
         }
         ps0 = 1;
@@ -698,64 +692,120 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
         // drain, then publish every round of step 0 at once
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int r = 0; p.handoff && wave == 0 && r < NR; r += 64)
+        for (int r = 0; p.handoff && wave == 4 && r < NR; r += 64)
             if (r + lane < NR) __hip_atomic_store(myflags + (r + lane) * 16 + cm.member, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#ifdef XPS_CL_STAMP
-    rt[3] = __builtin_amdgcn_s_memrealtime();
-#endif
 
     const int q_begin = ps0 * NQ, q_end = p.ps_end * NQ;
-    if (p.handoff && wave == 0) {
+    if (p.handoff && wave == 4) {
         // the first two sub-iterations (round 0, segments 0 and 1) are loaded without a look-ahead poll
         unsigned f0 = 0xffffffffu;
         if (lane < p.CS) f0 = __hip_atomic_load(myflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cl_wait(myflags, (unsigned)ps0, p.CS, lane, f0, p.status);
     }
     __syncthreads();
-    {
-        const unsigned char* src = dma_src(q_begin);
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_piece(src, q_begin, i);
+    if (!contract_role) {
+        dma_sub(q_begin);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    f32x4 acc[2];
-    f32x4 own[NTE];                  // finished k-half products of the round whose gate math is pending
+    if (contract_role) {
+        // ---------------- contraction waves ----------------
+        const int ut = cw / KSPLIT, kh = cw % KSPLIT;
+        const int j0 = cm.member * Cf::U + ut * 16;
+        const int kbase = kh * 256;
+        const float* __restrict__ WT = p.w_hh_t[dir];
+        ClWeights<BF> w;
+        {
+            const int jr = j0 + n;
+            const bool rlive = jr < H;
+            const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H + kbase;
+            const float* const seg[3] = {wrow, wrow + H, wrow + 2 * H};
+            w.load(seg, rlive, kq, H - kbase, WT);
+        }
+        f32x4 acc[2];
+        for (int q = q_begin; q < q_end; ++q) {
+            const int ps = q / NQ, rem = q - ps * NQ;
+            const int r = rem / 3, g = rem - 3 * r;
+            if (g == 0) {
+                acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[1] = acc[0];
+            }
+            const unsigned char* tb = smem + (q & 1) * TILE;
+            auto contract = [&](auto G) {
+                constexpr int gg = decltype(G)::value;
+                // one trial tile at a time (8 fragment registers live instead of 16: the kernel must fit 256 registers)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
+                            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
+                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[gg][c], bh, acc[tt], 0, 0, 0);
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bl, acc[tt], 0, 0, 0);
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bh, acc[tt], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.wf[gg][c][e], a4[e], acc[tt], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            if (g == 0) contract(std::integral_constant<int, 0>{});
+            else if (g == 1) contract(std::integral_constant<int, 1>{});
+            else contract(std::integral_constant<int, 2>{});
+            if (g == 2) {
+                // (double buffered by round parity: the gate-math waves read it during the next sub-iteration, the next
+                // write of the same buffer is six barriers away)
+                unsigned char* xw = xacc + ((((q / 3) & 1) * 4 + cw) * 2) * 1024 + lane * 16;
+                *reinterpret_cast<f32x4*>(xw) = acc[0];
+                *reinterpret_cast<f32x4*>(xw + 1024) = acc[1];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- gate-math / memory waves ----------------
     EpiIn ein[NTE];
     int pend_ps = -1, pend_r = 0;    // round whose gate math runs in the next sub-iteration
     auto finish = [&](int qlast) {   // qlast: the g == 2 sub-iteration of the pending round
 #pragma unroll
         for (int te = 0; te < NTE; ++te) {
-            f32x4 a = own[te];
+            const int tsel = KSPLIT == 2 ? (cw & 1) : te;
+            const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + lane * 16;
+            f32x4 a;
             if constexpr (KSPLIT == 2) {
-                const unsigned char* xr_ = xch + ((qlast / 3) & 1) * (4 * 3 * 1024) + (wave ^ 1) * (3 * 1024) + lane * 16;
-                a += *reinterpret_cast<const f32x4*>(xr_);
+                a = *reinterpret_cast<const f32x4*>(xa + ((2 * hut) * 2 + tsel) * 1024);
+                a += *reinterpret_cast<const f32x4*>(xa + ((2 * hut + 1) * 2 + tsel) * 1024);
+            } else {
+                a = *reinterpret_cast<const f32x4*>(xa + (cw * 2 + tsel) * 1024);
             }
             epilogue(pend_ps, pend_r, te, ein[te], a);
         }
     };
-#ifdef XPS_CL_STAMP
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, a_issue = 0, a_mfma = 0, a_poll = 0, a_commit = 0, a_bar = 0, a_epi = 0, c_begin = 0, c_end = 0;
-    CL_STAMP(c_begin)
-    rt[4] = __builtin_amdgcn_s_memrealtime();
-#endif
     for (int q = q_begin; q < q_end; ++q) {
         const int ps = q / NQ, rem = q - ps * NQ;
         const int r = rem / 3, g = rem - 3 * r;
-        CL_STAMP(c0)
-        // (1) the gate gradients stored during sub-iteration q - 1 (gate math of the round that ended at q - 2) were drained
-        //     before the last barrier
-        if (p.handoff && tid == 0 && g == 1 && q - 2 >= q_begin) {
+        // the gate gradients stored during sub-iteration q - 1 (gate math of the round that ended at q - 2) were drained
+        // before the last barrier
+        if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
             const int qp = q - 2;
             const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
             __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // (2) gate math of the round that finished its contraction in the previous sub-iteration
+        if (q + 1 < q_end) dma_sub(q + 1);
+        // gate math of the round that finished its contraction in the previous sub-iteration
         if (g == 0 && pend_ps >= 0) { finish(q - 1); pend_ps = -1; }
-        CL_STAMP(c1)
-        // (3) requests: inputs of this round's gate math, flags of the round after next
+        // requests: inputs of this round's gate math, flags of the round after next
         if (g == 1) {
 #pragma unroll
             for (int te = 0; te < NTE; ++te) epi_load(ps, r, te, ein[te]);
@@ -763,96 +813,15 @@ __global__ __launch_bounds__(256, 1) void gru_cluster_bwd_kernel(ClBwd p) {
         const int q2 = q + 2;
         const int ps2 = q2 / NQ, rem2 = q2 - ps2 * NQ;
         const int r2 = rem2 / 3;
-        const bool do_poll = p.handoff && wave == 0 && q2 < q_end && rem2 % 3 == 0;
+        const bool do_poll = p.handoff && wave == 4 && q2 < q_end && rem2 % 3 == 0;
         unsigned fl = 0xffffffffu;
         if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g == 0) {
-            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[1] = acc[0];
-        }
-
-        // (4) contraction of segment g, DMA pieces of the next sub-iteration between the chunks
-        const bool has_next = q + 1 < q_end;
-        const unsigned char* src = dma_src(has_next ? q + 1 : q);
-        const unsigned char* tb = smem + (q & 1) * TILE;
-        auto contract = [&](auto G) {
-            constexpr int gg = decltype(G)::value;
-            if constexpr (BF) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (has_next) {
-#pragma unroll
-                        for (int i = c * PPW / 8; i < (c + 1) * PPW / 8; ++i) dma_piece(src, q + 1, i);
-                    }
-                    bf16x8 bh[2], bl[2];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
-                        bh[tt] = *reinterpret_cast<const bf16x8*>(rp);
-                        bl[tt] = *reinterpret_cast<const bf16x8*>(rp + PS);
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[gg][c], bh[tt], acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bl[tt], acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bh[tt], acc[tt], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (has_next) {
-#pragma unroll
-                        for (int i = c * PPW / 16; i < (c + 1) * PPW / 16; ++i) dma_piece(src, q + 1, i);
-                    }
-                    f32x4 a4[2];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-                        a4[tt] = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt)
-                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.wf[gg][c][e], a4[tt][e], acc[tt], 0, 0, 0);
-                }
-            }
-        };
-        if (g == 0) contract(std::integral_constant<int, 0>{});
-        else if (g == 1) contract(std::integral_constant<int, 1>{});
-        else contract(std::integral_constant<int, 2>{});
-        CL_STAMP(c2)
-
-        // (5) last segment: hand the other tile's partial sums to the k-partner; drain; barrier
-        if (g == 2) {
-            if constexpr (KSPLIT == 2) {
-                unsigned char* xw = xch + ((q / 3) & 1) * (4 * 3 * 1024) + wave * (3 * 1024) + lane * 16;
-                *reinterpret_cast<f32x4*>(xw) = kh ? acc[0] : acc[1];
-                own[0] = kh ? acc[1] : acc[0];
-            } else {
-                own[0] = acc[0]; own[NTE - 1] = acc[1];
-            }
-            pend_ps = ps; pend_r = r;
-        }
+        if (g == 2) { pend_ps = ps; pend_r = r; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed, its stores are complete
-        CL_STAMP(c3)
         if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
-        CL_STAMP(c4)
         __syncthreads();
-        CL_STAMP(c5)
-        CL_STAMP(c6)
-        CL_ACC(a_epi, c0, c1) CL_ACC(a_issue, c1, c1) CL_ACC(a_mfma, c1, c2) CL_ACC(a_commit, c2, c3) CL_ACC(a_poll, c3, c4) CL_ACC(a_bar, c4, c5)
     }
     if (pend_ps >= 0) finish(q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
-#ifdef XPS_CL_STAMP
-    CL_STAMP(c_end)
-    if (lane == 0) {
-        const int wid = (blockIdx.x * 4 + wave) & 1023;
-        g_clstamp[wid * 8 + 0] = a_issue; g_clstamp[wid * 8 + 1] = a_mfma; g_clstamp[wid * 8 + 2] = a_poll; g_clstamp[wid * 8 + 3] = a_commit;
-        g_clstamp[wid * 8 + 4] = a_bar; g_clstamp[wid * 8 + 5] = a_epi; g_clstamp[wid * 8 + 6] = c_begin; g_clstamp[wid * 8 + 7] = c_end;
-        rt[5] = __builtin_amdgcn_s_memrealtime();
-        for (int i = 0; i < 6; ++i) g_clstamp[8192 + wid * 8 + i] = rt[i];
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -979,12 +948,12 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
         if (!cl_set_lds(kernel, lds)) return false;
         if (persistent) {
             p.s_begin = 0; p.s_end = T; p.handoff = 1;
-            hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+            hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
         } else {
             p.handoff = 0;
             for (int s = 0; s < T; ++s) {
                 p.s_begin = s; p.s_end = s + 1;
-                hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+                hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
             }
         }
         return true;
@@ -1031,12 +1000,12 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
         if (!cl_set_lds(kernel, lds)) return false;
         if (persistent) {
             p.ps_begin = 0; p.ps_end = ps_total; p.handoff = 1;
-            hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+            hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
         } else {
             p.handoff = 0;
             for (int ps = 0; ps < ps_total; ++ps) {
                 p.ps_begin = ps; p.ps_end = ps + 1;
-                hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(256), lds, st, p);
+                hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
             }
         }
         return true;
