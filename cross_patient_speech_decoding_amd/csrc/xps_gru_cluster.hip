@@ -70,7 +70,7 @@ struct ClCfg {
 #ifdef XPS_CL_STAMP
 // Diagnostic build only (tools/stamp_cluster.py; never shipped): per-wave cycle sums of the loop segments, written to a
 // buffer of their own that no kernel reads.
-__device__ unsigned long long g_clstamp[2 * 1024 * 8];
+__device__ unsigned long long g_clstamp[2048 * 8];
 #define CL_STAMP(var)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
@@ -158,8 +158,9 @@ __device__ inline ClMap cl_map(int CS) {
 }
 
 // one 1-KiB LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses (L1 bypassed: sc1) to LDS [lds_dst, +1024).
-// Inline asm so that the compiler does not order its LDS reads of the OTHER buffer behind it; completion is waited for
-// by hand (s_waitcnt vmcnt(0) before the round's barrier).  M0 is saved and restored (compiler-reserved).
+// Inline asm: with the builtin the compiler orders EVERY later LDS read of the wave behind the piece with vmcnt(0).  Only
+// the two mover waves issue pieces; apart from them they issue flag stores / polls, and they drain with vmcnt(0) before the
+// round's barrier.  M0 is saved and restored (compiler-reserved).
 __device__ inline void cl_dma_piece(const unsigned char* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
@@ -169,6 +170,24 @@ __device__ inline void cl_dma_piece(const unsigned char* gsrc, unsigned lds_dst)
 __device__ inline unsigned cl_lds_base(const unsigned char* smem) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) unsigned char*)smem;
 }
+
+// s_waitcnt vmcnt(n): all but this wave's n YOUNGEST vector-memory operations are done (they retire in issue order).  The
+// gate-math waves issue per round, in this order (compiler fences between the groups): flag store / poll load, the
+// LDS-DMA pieces of the next operand, the exchange stores, then the output stores and the loads for a later round.  Before the
+// hand-off barrier only the first groups must be complete, so the wait leaves exactly the operations issued AFTER the
+// exchange stores in flight.  n is the number of such operations the code issues unconditionally (stores of dead lanes are
+// dropped by the buffer range check, not branched around); a smaller n is always safe, it only waits longer.
+__device__ inline void cl_wait_vmcnt(int n) {
+    switch (n) {
+#define CL_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        CL_VMCNT_CASE(1) CL_VMCNT_CASE(2) CL_VMCNT_CASE(4) CL_VMCNT_CASE(5) CL_VMCNT_CASE(6) CL_VMCNT_CASE(7) CL_VMCNT_CASE(8)
+        CL_VMCNT_CASE(9) CL_VMCNT_CASE(10) CL_VMCNT_CASE(12) CL_VMCNT_CASE(14) CL_VMCNT_CASE(18)
+#undef CL_VMCNT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+#define CL_FENCE() asm volatile("" ::: "memory")
+constexpr unsigned CL_OOB = 0xFFFFFFF0u;       // buffer offset beyond every descriptor's range: the access is dropped
 
 // resident weight fragments of one wave: rows = units j0 + n of `wsrc` rows (row stride ld floats), three k segments of 256
 template <bool BF>
@@ -229,29 +248,30 @@ struct ClFwd {
     int s_begin, s_end, handoff;
 };
 
-// 512 threads: waves 0-3 CONTRACT (resident W_hh fragments, LDS operand reads, MFMA, nothing else), waves 4-7 do everything
-// else (LDS-DMA of the next round's operand, gate math of the previous round, global loads / stores, flags): every SIMD holds
-// one wave of each kind, so the matrix pipe never waits for a vector-memory issue slot or for the gate math.
-// Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster); between two barriers
-//   contraction wave (ut, kh): h_{t-1} W_hh^T of two trial tiles over its k-half -> xacc (once the gate-math waves have taken
-//                     the previous round's products out: one LDS word per gate-math wave, no second barrier);
-//   gate-math wave h: publishes round it - 2 (its exchange rows were drained before the last barrier), issues its DMA pieces
-//                     of round it + 1 into the other buffer, finishes round it - 1 (sums the two k-halves from xacc, gates,
-//                     hidden update, output + exchange stores), requests the gate inputs of round it + 1 and the flags of
-//                     round it + 2, then drains (vmcnt(0): DMA landed, stores complete) before the barrier.
+// 512 threads, three kinds of waves (every SIMD holds a contraction wave and one of the others, so the matrix pipe never
+// waits for a vector-memory issue slot, a memory latency or the gate math):
+//   waves 0-3  CONTRACT: resident W_hh fragments (unit tile ut = w / 2, k-half kh = w % 2), LDS operand reads, MFMA, products to
+//              xacc; nothing else;
+//   waves 4-5  MOVE: the LDS-DMA pieces of the next round's operand (32 each), the flags (wave 4); they drain with vmcnt(0)
+//              (only L2-served operations are ever in flight there);
+//   waves 6-7  GATES (unit tile w - 6, both trial tiles): sum the two k-halves from xacc, gate math, exchange rows, outputs,
+//              requests for the gate inputs of later rounds.  Their vector-memory operations are all visible to the compiler
+//              (its waits for the input loads are exact) and only the exchange rows must be complete at the barrier
+//              (cl_wait_vmcnt): output stores and input loads stay in flight across rounds.
+// Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster); one barrier per round.  During round it: contraction of
+// round it (buffer it & 1), pieces of round it + 1 into the other buffer, gate math of round it - 1, flag of round it - 2
+// (its exchange rows were complete before the last barrier), poll of the flags of round it + 2.
 template <int KSPLIT, bool BF>
 __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
+    static_assert(KSPLIT == 2, "the cluster kernels cover 256 < H <= 512");
     using Cf = ClCfg<KSPLIT, BF, 1>;
-    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 4;
-    constexpr int NTE = KSPLIT == 2 ? 1 : 2;          // trial tiles whose gate math one wave runs per round
+    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xacc = smem + 2 * TILE;
-    unsigned* consumed = reinterpret_cast<unsigned*>(xacc + Cf::XACC_BYTES);      // [4] rounds taken out of xacc, per gate-math wave
+    unsigned* consumed = reinterpret_cast<unsigned*>(xacc + Cf::XACC_BYTES);      // [2] rounds taken out of xacc, per gate wave
     const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool contract_role = wave < 4;
-    const int cw = wave & 3;
     const int n = lane & 15, kq = lane >> 4;
     const ClMap cm = cl_map(p.CS);
     const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
@@ -260,33 +280,40 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     const int m_base = blk * p.Mc;
     const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
-    if (tid < 4) consumed[tid] = 0u;
+    if (tid < 2) consumed[tid] = 0u;
 
     // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
     const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
 
-    // this wave's share of round itn's operand (gate-math waves): PPW pieces -> buffer itn & 1
+    // a mover wave's half of round itn's operand: PPW pieces -> buffer itn & 1
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
     auto dma_round = [&](int itn) {
+        const int mv = wave - 4;
         const int sn = itn / NR, rn = itn - sn * NR;
-        const unsigned char* src = xb + (size_t)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (KP * 4) + (size_t)(cw * PPW) * 1024 + lane * 16;
+        const unsigned char* src = xb + (size_t)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (KP * 4) + (size_t)(mv * PPW) * 1024 + lane * 16;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            // piece index cw * PPW + i; PPW is even, so the plane / half of a piece is that of i
-            const unsigned dst = lds0 + (unsigned)((itn & 1) * TILE) +
-                                 (unsigned)(Cf::PPT == 2 ? ((cw * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (cw * PPW + i) * TS);
+            // piece index mv * PPW + i; PPW is even, so the plane / half of a piece is that of i
+            const unsigned dst = lds0 + (unsigned)((itn & 1) * TILE) + (unsigned)(((mv * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024));
             cl_dma_piece(src + i * 1024, dst);
         }
     };
-    if (!contract_role) {
+    if (wave == 4 || wave == 5) {
         dma_round(it_begin);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#ifdef XPS_CL_STAMP
+    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, s_bar = 0, s_work = 0, s_drain = 0;
+    CL_STAMP(sb2)
+#define CL_STORE_STAMPS() if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; }
+#else
+#define CL_STORE_STAMPS()
+#endif
 
-    if (contract_role) {
+    if (wave < 4) {
         // ---------------- contraction waves ----------------
-        const int ut = cw / KSPLIT, kh = cw % KSPLIT;
+        const int ut = wave >> 1, kh = wave & 1;
         const int j0 = cm.member * Cf::U + ut * 16;
         const int kbase = kh * 256;
         const float* __restrict__ W = p.w_hh[dir];
@@ -299,8 +326,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
                                          W + (long long)(2 * H + jrc) * H + kbase};
             w.load(seg, rlive, kq, H - kbase, W);
         }
-        // gate-math waves that read this wave's products: (KSPLIT == 2) waves 2 ut and 2 ut + 1; (KSPLIT == 1) wave cw
-        const int c0 = KSPLIT == 2 ? (cw & ~1) : cw, c1 = KSPLIT == 2 ? (cw | 1) : cw;
+        CL_STAMP(sb2)
         for (int it = it_begin; it < it_end; ++it) {
             const unsigned char* tb = smem + (it & 1) * TILE;
             f32x4 acc[2][3];
@@ -336,29 +362,67 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             // the previous round's products must have been taken out of xacc (they were, two thousand cycles ago: one look)
             if (it > it_begin) {
                 const unsigned want = (unsigned)(it - it_begin);
-                while (__hip_atomic_load(consumed + c0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
-                       __hip_atomic_load(consumed + c1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
-                    __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(consumed + ut, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
-                    *reinterpret_cast<f32x4*>(xacc + ((cw * 2 + tt) * 3 + g) * 1024 + lane * 16) = acc[tt][g];
+                    *reinterpret_cast<f32x4*>(xacc + ((wave * 2 + tt) * 3 + g) * 1024 + lane * 16) = acc[tt][g];
+            CL_STAMP(sb0)
             __syncthreads();
+            CL_STAMP(sb1)
+            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb0)
+#ifdef XPS_CL_STAMP
+            sb2 = sb1;
+#endif
         }
+        CL_STORE_STAMPS()
         return;
     }
 
-    // ---------------- gate-math / memory waves ----------------
-    const int hut = KSPLIT == 2 ? (cw >> 1) : cw;      // unit tile of this wave's gate math
+    if (wave < 6) {
+        // ---------------- mover waves ----------------
+        for (int it = it_begin; it < it_end; ++it) {
+            // flag of round it - 2: the gate waves stored its exchange rows during round it - 1 and had them complete before
+            // the last barrier
+            if (p.handoff && wave == 4 && lane == 0 && it >= it_begin + 2) {
+                const int itp = it - 2;
+                const int sp = itp / NR, rp = itp - sp * NR;
+                __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (it + 1 < it_end) dma_round(it + 1);
+            const int it2 = it + 2;
+            const int s2 = it2 / NR, r2 = it2 - s2 * NR;
+            const bool do_poll = p.handoff && wave == 4 && it2 < it_end && s2 > p.s_begin;
+            unsigned fl = 0xffffffffu;
+            if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            CL_STAMP(sb3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
+            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)s2, p.CS, lane, fl, p.status);
+            CL_STAMP(sb0)
+            __syncthreads();
+            CL_STAMP(sb1)
+            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb0)
+#ifdef XPS_CL_STAMP
+            sb2 = sb1;
+#endif
+        }
+        CL_STORE_STAMPS()
+        return;
+    }
+
+    // ---------------- gate waves ----------------
+    const int hut = wave - 6;                          // unit tile
     const int j0 = cm.member * Cf::U + hut * 16;
     const int ju = j0 + 4 * kq;                        // this lane's four units
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
     const float* __restrict__ gi = p.gi + (long long)dir * T * B * 3 * H;
+    const bool has_saved = p.saved != nullptr;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y_ext, 0, (unsigned)((long long)(T + 2) * B * ldy * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(p.saved, 0, has_saved ? (unsigned)((long long)p.ndir * T * B * 4 * H * 4) : 0u, RSRC_FLAGS);
     f32x4 bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -366,12 +430,11 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         if (!ulive) bias[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     struct EpiIn { f32x4 gr, gz, gn; u32x4 hp; };
-    auto epi_load = [&](int itn, int te, EpiIn& in) {
+    auto epi_load = [&](int itn, int te, EpiIn& in) {      // 4 loads, always issued
         const int sn = itn / NR, rn = itn - sn * NR;
         const int t = (dir == 0) ? sn : T - 1 - sn;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
-        const int b = m_base + 32 * rn + 16 * tsel + n;
+        const int b = m_base + 32 * rn + 16 * te + n;
         const int bc = b < B ? b : B - 1;
         const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
         in.gr = *reinterpret_cast<const f32x4*>(gp);
@@ -381,110 +444,132 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         in.hp = __builtin_amdgcn_raw_buffer_load_b128(yr, (unsigned)((((long long)slot_prev * B + bc) * ldy + dir * H + juc) * 4), 0, AUX_SC1);
     };
     // gates + hidden update of round itn for this lane's trial and four units; a_* = complete pre-activation products
-    auto epilogue = [&](int itn, int te, const EpiIn& in, f32x4 a_r, f32x4 a_z, f32x4 a_n) {
+    struct EpiOut { f32x4 o, rg, zg, ng, qv; };
+    auto epi_compute = [&](int itn, int te, const EpiIn& in, f32x4 a_r, f32x4 a_z, f32x4 a_n, EpiOut& out) {
         const int sn = itn / NR, rn = itn - sn * NR;
-        const int t = (dir == 0) ? sn : T - 1 - sn;
-        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
-        const int b = m_base + 32 * rn + 16 * tsel + n;
+        const int b = m_base + 32 * rn + 16 * te + n;
         const bool live = b < B && ulive;
         const f32x4 hp = __builtin_bit_cast(f32x4, in.hp);      // (whole vector: a bit_cast of ONE element reads element 0)
-        f32x4 o, rg, zg, ng, qv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rg[i] = cl_sigmoid(in.gr[i] + a_r[i] + bias[0][i]);
-            zg[i] = cl_sigmoid(in.gz[i] + a_z[i] + bias[1][i]);
-            qv[i] = a_n[i] + bias[2][i];
-            ng[i] = cl_tanh(in.gn[i] + rg[i] * qv[i]);
-            o[i] = live ? ng[i] + zg[i] * (hp[i] - ng[i]) : 0.f;
-        }
-        if (sn + 1 < T) {
-            const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
-            if constexpr (BF) {
-                bf16x4 sh, sl;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(o[i], a, c); sh[i] = a; sl[i] = c; }
-                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
-                if (fast) {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
-                }
-            } else {
-                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
-                if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, AUX_SC1);
-            }
-        }
-        if (live) {
-            *reinterpret_cast<f32x4*>(p.y_ext + ((long long)(t + 1) * B + b) * ldy + dir * H + ju) = o;
-            if (p.saved) {
-                float* sv = p.saved + (((long long)dir * T + t) * B + b) * 4 * H + ju;
-                *reinterpret_cast<f32x4*>(sv) = rg;
-                *reinterpret_cast<f32x4*>(sv + H) = zg;
-                *reinterpret_cast<f32x4*>(sv + 2 * H) = ng;
-                *reinterpret_cast<f32x4*>(sv + 3 * H) = qv;
-            }
+            out.rg[i] = cl_sigmoid(in.gr[i] + a_r[i] + bias[0][i]);
+            out.zg[i] = cl_sigmoid(in.gz[i] + a_z[i] + bias[1][i]);
+            out.qv[i] = a_n[i] + bias[2][i];
+            out.ng[i] = cl_tanh(in.gn[i] + out.rg[i] * out.qv[i]);
+            out.o[i] = live ? out.ng[i] + out.zg[i] * (hp[i] - out.ng[i]) : 0.f;
         }
     };
-    // products of the finished round for this wave's tile(s): k-low half + k-high half (KSPLIT == 2), taken out of xacc
-    f32x4 prod[NTE][3];
+    // exchange rows of the next step (every lane stores: rows of pad trials / pad units carry zeros)
+    auto epi_exchange = [&](int itn, int te, const EpiOut& out) {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        if (sn + 1 >= T) return;
+        const int b = m_base + 32 * rn + 16 * te + n;
+        const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
+        if constexpr (BF) {
+            bf16x4 sh, sl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(out.o[i], a, c); sh[i] = a; sl[i] = c; }
+            const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
+            if (fast) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+            }
+        } else {
+            const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
+            if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.o), xr, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.o), xr, off, 0, AUX_SC1);
+        }
+    };
+    // outputs: h_t and (training) the saved gates; 1 or 5 stores, ALWAYS issued (dead lanes: offset out of range, dropped)
+    auto epi_outputs = [&](int itn, int te, const EpiOut& out) {
+        const int sn = itn / NR, rn = itn - sn * NR;
+        const int t = (dir == 0) ? sn : T - 1 - sn;
+        const int b = m_base + 32 * rn + 16 * te + n;
+        const bool live = b < B && ulive;
+        const unsigned yo = live ? (unsigned)((((long long)(t + 1) * B + b) * ldy + dir * H + ju) * 4) : CL_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.o), yr, yo, 0, 0);
+        if (has_saved) {
+            const unsigned so = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 4 * H + ju) * 4) : CL_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.rg), sr, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.zg), sr, live ? so + (unsigned)H * 4u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.ng), sr, live ? so + (unsigned)H * 8u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.qv), sr, live ? so + (unsigned)H * 12u : CL_OOB, 0, 0);
+        }
+    };
+    // products of the finished round for both trial tiles: k-low half + k-high half, taken out of xacc
+    f32x4 prod[2][3];
     auto take_products = [&](int rounds_done) {
 #pragma unroll
-        for (int te = 0; te < NTE; ++te) {
-            const int tsel = KSPLIT == 2 ? (cw & 1) : te;
+        for (int te = 0; te < 2; ++te)
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                if constexpr (KSPLIT == 2) {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut) * 2 + tsel) * 3 + g) * 1024 + lane * 16);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut + 1) * 2 + tsel) * 3 + g) * 1024 + lane * 16);
-                    prod[te][g] = lo + hi;
-                } else {
-                    prod[te][g] = *reinterpret_cast<const f32x4*>(xacc + ((cw * 2 + tsel) * 3 + g) * 1024 + lane * 16);
-                }
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut) * 2 + te) * 3 + g) * 1024 + lane * 16);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut + 1) * 2 + te) * 3 + g) * 1024 + lane * 16);
+                prod[te][g] = lo + hi;
             }
-        }
         // the reads above must have returned before the contraction waves may overwrite xacc
-        if (lane == 0) __hip_atomic_store(consumed + cw, (unsigned)rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(consumed + hut, (unsigned)rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    EpiIn ein[NTE], ein_next[NTE];
+    // gate inputs live in two register slots (round parity relative to the launch's first round): requested during round
+    // it - 1, used during round it + 1.  The loop body is instantiated per slot so that no copy (which would wait for the
+    // loads) and no dynamic register index is needed.
+    EpiIn ein[2][2];
 #pragma unroll
-    for (int te = 0; te < NTE; ++te) epi_load(it_begin, te, ein_next[te]);
-    for (int it = it_begin; it < it_end; ++it) {
-        // the exchange rows of round it - 2 were stored during round it - 1 and drained before the last barrier
-        if (p.handoff && wave == 4 && lane == 0 && it >= it_begin + 2) {
-            const int itp = it - 2;
-            const int sp = itp / NR, rp = itp - sp * NR;
-            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (it + 1 < it_end) dma_round(it + 1);
+    for (int te = 0; te < 2; ++te) epi_load(it_begin, te, ein[0][te]);
+    auto round_body = [&](int it, auto SLOT) {
+        constexpr int cur = decltype(SLOT)::value;            // slot of round it (and of round it + 2); round it - 1 / it + 1: the other
+        int younger = 0;                                    // operations issued after the exchange stores (see cl_wait_vmcnt)
         if (it > it_begin) {
             take_products(it - it_begin);
+            EpiOut out[2];
 #pragma unroll
-            for (int te = 0; te < NTE; ++te) epilogue(it - 1, te, ein[te], prod[te][0], prod[te][1], prod[te][2]);
+            for (int te = 0; te < 2; ++te) epi_compute(it - 1, te, ein[cur ^ 1][te], prod[te][0], prod[te][1], prod[te][2], out[te]);
+            CL_FENCE();
+#pragma unroll
+            for (int te = 0; te < 2; ++te) epi_exchange(it - 1, te, out[te]);
+            CL_FENCE();
+#pragma unroll
+            for (int te = 0; te < 2; ++te) epi_outputs(it - 1, te, out[te]);
+            younger += 2 * (has_saved ? 5 : 1);
         }
-#pragma unroll
-        for (int te = 0; te < NTE; ++te) ein[te] = ein_next[te];
+        CL_FENCE();
         if (it + 1 < it_end) {
 #pragma unroll
-            for (int te = 0; te < NTE; ++te) epi_load(it + 1, te, ein_next[te]);
+            for (int te = 0; te < 2; ++te) epi_load(it + 1, te, ein[cur ^ 1][te]);
+            younger += 2 * 4;
         }
-        const int it2 = it + 2;
-        const int s2 = it2 / NR, r2 = it2 - s2 * NR;
-        const bool do_poll = p.handoff && wave == 4 && it2 < it_end && s2 > p.s_begin;
-        unsigned fl = 0xffffffffu;
-        if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed, its stores are complete
-        if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)s2, p.CS, lane, fl, p.status);
+        CL_FENCE();
+        CL_STAMP(sb3)
+        cl_wait_vmcnt(younger);                             // exchange rows complete; outputs / next inputs stay in flight
+        CL_STAMP(sb0)
         __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb0)
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
+    };
+    for (int it = it_begin; it < it_end; it += 2) {
+        round_body(it, std::integral_constant<int, 0>{});
+        if (it + 1 < it_end) round_body(it + 1, std::integral_constant<int, 1>{});
     }
     if (it_end > it_begin) {                                    // (outputs of the launch's last round; nobody waits for its flag)
         take_products(it_end - it_begin);
+        EpiOut out[2];
+        const bool odd = ((it_end - 1 - it_begin) & 1) != 0;
 #pragma unroll
-        for (int te = 0; te < NTE; ++te) epilogue(it_end - 1, te, ein[te], prod[te][0], prod[te][1], prod[te][2]);
+        for (int te = 0; te < 2; ++te) {
+            if (odd) epi_compute(it_end - 1, te, ein[1][te], prod[te][0], prod[te][1], prod[te][2], out[te]);
+            else epi_compute(it_end - 1, te, ein[0][te], prod[te][0], prod[te][1], prod[te][2], out[te]);
+            epi_exchange(it_end - 1, te, out[te]);
+            epi_outputs(it_end - 1, te, out[te]);
+        }
     }
+    CL_STORE_STAMPS()
 }
 
 // h0 -> slots of y_ext and parity 0 of the exchange buffer (all Bp rows, all KP columns: pads are zero)
@@ -545,18 +630,21 @@ struct ClBwd {
     int ps_begin, ps_end, ps_total, handoff;
 };
 
+// Same three wave roles as the forward kernel.  Sub-iteration q = (ps, round r, gate segment g): contraction waves
+// accumulate segment g of round r (buffer q & 1) and hand the finished products over after g == 2 (xacc, double buffered by
+// round parity); movers stream sub-iteration q + 1; gate waves act once per round, during its first sub-iteration: gate
+// math of the PREVIOUS round (products from xacc, inputs requested one round earlier), exchange rows, outputs, then the
+// requests for THIS round's inputs.
 template <int KSPLIT, bool BF>
 __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
+    static_assert(KSPLIT == 2, "the cluster kernels cover 256 < H <= 512");
     using Cf = ClCfg<KSPLIT, BF, 3>;
-    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 4;
-    constexpr int NTE = KSPLIT == 2 ? 1 : 2;
+    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xacc = smem + 2 * TILE;              // [round parity 2][contraction wave 4][tile 2] x 1 KiB
     const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool contract_role = wave < 4;
-    const int cw = wave & 3;
     const int n = lane & 15, kq = lane >> 4;
     const ClMap cm = cl_map(p.CS);
     const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
@@ -567,64 +655,73 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
     const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
 
-    // gate-math waves: unit tile, units, buffers
-    const int hut = KSPLIT == 2 ? (cw >> 1) : cw;
+    // gate waves: unit tile, units, buffers
+    const int hut = wave >= 6 ? wave - 6 : 0;
     const int ju = cm.member * Cf::U + hut * 16 + 4 * kq;
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgi, 0, (unsigned)((long long)p.ndir * T * B * 3 * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(p.dghn, 0, (unsigned)((long long)p.ndir * T * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
+    const bool has_dy = p.dy != nullptr;
 
     // sub-iteration q = ps * NQ + r * 3 + g reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1)
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
     auto dma_sub = [&](int qn) {
+        const int mv = wave - 4;
         const int psn = qn / NQ, rem = qn - psn * NQ;
         const size_t chunk = (size_t)(((((psn - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + rem / 3) * 3 + rem % 3);
-        const unsigned char* src = xb + chunk * Cf::CHUNK_BYTES + (size_t)(cw * PPW) * 1024 + lane * 16;
+        const unsigned char* src = xb + chunk * Cf::CHUNK_BYTES + (size_t)(mv * PPW) * 1024 + lane * 16;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const unsigned dst = lds0 + (unsigned)((qn & 1) * TILE) +
-                                 (unsigned)(Cf::PPT == 2 ? ((cw * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024) : (cw * PPW + i) * TS);
+            const unsigned dst = lds0 + (unsigned)((qn & 1) * TILE) + (unsigned)(((mv * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024));
             cl_dma_piece(src + i * 1024, dst);
         }
     };
 
     struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
-    auto epi_load = [&](int ps, int r, int te, EpiIn& in) {
+    // inputs of the gate math of (ps, r), trial tile te: returns the number of loads issued (always the same for a given ps)
+    auto epi_load = [&](int ps, int r, int te, EpiIn& in) -> int {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
-        const int b = m_base + 32 * r + 16 * tsel + n;
+        const int b = m_base + 32 * r + 16 * te + n;
         const int bc = b < B ? b : B - 1;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        int nload = 0;
         in.keep = (u32x4){0u, 0u, 0u, 0u};
-        if (ps > 0) in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1);
-        else if (p.dhn) in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc));
+        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1); ++nload; }
+        else if (p.dhn) { in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc)); ++nload; }
         if (ps < T) {
-            in.dy = p.dy ? *reinterpret_cast<const f32x4*>(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc) : z4;
+            in.dy = z4;
+            if (has_dy) { in.dy = *reinterpret_cast<const f32x4*>(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc); ++nload; }
             const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
             in.rg = *reinterpret_cast<const f32x4*>(sv);
             in.zg = *reinterpret_cast<const f32x4*>(sv + H);
             in.ng = *reinterpret_cast<const f32x4*>(sv + 2 * H);
             in.q = *reinterpret_cast<const f32x4*>(sv + 3 * H);
             in.hp = *reinterpret_cast<const f32x4*>(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
+            nload += 5;
         } else {
             in.dy = z4; in.rg = z4; in.zg = z4; in.ng = z4; in.q = z4; in.hp = z4;
         }
+        return nload;
     };
-    // gate gradients of processing step ps for (round r, this lane's trial and units); acc = dgh_{ps-1} W_hh (own units)
-    auto epilogue = [&](int ps, int r, int te, const EpiIn& in, const f32x4& acc) {
+    // gate gradients of processing step ps for (round r, tile te, this lane's trial and units); acc = dgh_{ps-1} W_hh (own units).
+    // Stores: the exchange rows first (group B), then the outputs (group C, always issued: dead lanes are dropped by the range
+    // check); returns the number of group-C stores.
+    auto epilogue = [&](int ps, int r, int te, const EpiIn& in, const f32x4& acc) -> int {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
-        const int tsel = KSPLIT == 2 ? (cw & 1) : te;
-        const int b = m_base + 32 * r + 16 * tsel + n;
+        const int b = m_base + 32 * r + 16 * te + n;
         const bool live = b < B && ulive;
         f32x4 carry = __builtin_bit_cast(f32x4, in.keep);             // (whole vector: a bit_cast of ONE element reads element 0)
         if (ps > 0) carry += acc;
         if (ps == T) {
-            if (live && p.dh0) *reinterpret_cast<f32x4*>(p.dh0 + ((long long)dir * B + b) * H + ju) = carry;
-            return;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, carry), hr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+            return 1;
         }
         f32x4 dar, daz, dan, danr, keep;
 #pragma unroll
@@ -642,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         }
         if (ps + 1 < p.ps_total) {                      // someone will contract these gradients
             const unsigned chunk0 = (unsigned)((((ps & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r) * 3);
-            const unsigned rowoff = (unsigned)(16 * tsel + n) * (unsigned)(KP * 4);
+            const unsigned rowoff = (unsigned)(16 * te + n) * (unsigned)(KP * 4);
             const f32x4* gsrc[3] = {&dar, &daz, &danr};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -664,23 +761,23 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                 }
             }
         }
-        if (live) {
-            float* o = p.dgi + (((long long)dir * T + t) * B + b) * 3 * H + ju;
-            *reinterpret_cast<f32x4*>(o) = dar;
-            *reinterpret_cast<f32x4*>(o + H) = daz;
-            *reinterpret_cast<f32x4*>(o + 2 * H) = dan;
-            *reinterpret_cast<f32x4*>(p.dghn + (((long long)dir * T + t) * B + b) * H + ju) = danr;
-            *reinterpret_cast<f32x4*>(p.keep + ((long long)dir * B + b) * H + ju) = keep;
-        }
+        CL_FENCE();
+        const unsigned go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dar), gr, go, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+        return 5;
     };
 
     int ps0 = p.ps_begin;
     if (ps0 == 0) {
-        // first processing step: no contraction, the running gradient starts from dhn (or zero); gate-math waves only
-        if (!contract_role) {
+        // first processing step: no contraction, the running gradient starts from dhn (or zero); gate waves only
+        if (wave >= 6) {
             for (int r = 0; r < NR; ++r) {
 #pragma unroll
-                for (int te = 0; te < NTE; ++te) {
+                for (int te = 0; te < 2; ++te) {
                     EpiIn in;
                     epi_load(0, r, te, in);
                     epilogue(0, r, te, in, (f32x4){0.f, 0.f, 0.f, 0.f});
@@ -704,15 +801,15 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         cl_wait(myflags, (unsigned)ps0, p.CS, lane, f0, p.status);
     }
     __syncthreads();
-    if (!contract_role) {
+    if (wave == 4 || wave == 5) {
         dma_sub(q_begin);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    if (contract_role) {
+    if (wave < 4) {
         // ---------------- contraction waves ----------------
-        const int ut = cw / KSPLIT, kh = cw % KSPLIT;
+        const int ut = wave >> 1, kh = wave & 1;
         const int j0 = cm.member * Cf::U + ut * 16;
         const int kbase = kh * 256;
         const float* __restrict__ WT = p.w_hh_t[dir];
@@ -763,9 +860,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             else if (g == 1) contract(std::integral_constant<int, 1>{});
             else contract(std::integral_constant<int, 2>{});
             if (g == 2) {
-                // (double buffered by round parity: the gate-math waves read it during the next sub-iteration, the next
-                // write of the same buffer is six barriers away)
-                unsigned char* xw = xacc + ((((q / 3) & 1) * 4 + cw) * 2) * 1024 + lane * 16;
+                // (double buffered by round parity: the gate waves read it during the next sub-iteration, the next write
+                // of the same buffer is six barriers away)
+                unsigned char* xw = xacc + ((((q / 3) & 1) * 4 + wave) * 2) * 1024 + lane * 16;
                 *reinterpret_cast<f32x4*>(xw) = acc[0];
                 *reinterpret_cast<f32x4*>(xw + 1024) = acc[1];
             }
@@ -774,51 +871,61 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         return;
     }
 
-    // ---------------- gate-math / memory waves ----------------
-    EpiIn ein[NTE];
-    int pend_ps = -1, pend_r = 0;    // round whose gate math runs in the next sub-iteration
-    auto finish = [&](int qlast) {   // qlast: the g == 2 sub-iteration of the pending round
-#pragma unroll
-        for (int te = 0; te < NTE; ++te) {
-            const int tsel = KSPLIT == 2 ? (cw & 1) : te;
-            const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + lane * 16;
-            f32x4 a;
-            if constexpr (KSPLIT == 2) {
-                a = *reinterpret_cast<const f32x4*>(xa + ((2 * hut) * 2 + tsel) * 1024);
-                a += *reinterpret_cast<const f32x4*>(xa + ((2 * hut + 1) * 2 + tsel) * 1024);
-            } else {
-                a = *reinterpret_cast<const f32x4*>(xa + (cw * 2 + tsel) * 1024);
+    if (wave < 6) {
+        // ---------------- mover waves ----------------
+        for (int q = q_begin; q < q_end; ++q) {
+            const int rem = q % NQ;
+            const int g = rem % 3;
+            // the gate waves stored the exchange rows of the round that ended at q - 2 during sub-iteration q - 1 and had them
+            // complete before the last barrier
+            if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
+                const int qp = q - 2;
+                const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
+                __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            epilogue(pend_ps, pend_r, te, ein[te], a);
+            if (q + 1 < q_end) dma_sub(q + 1);
+            const int q2 = q + 2;
+            const int ps2 = q2 / NQ, rem2 = q2 - ps2 * NQ;
+            const int r2 = rem2 / 3;
+            const bool do_poll = p.handoff && wave == 4 && q2 < q_end && rem2 % 3 == 0;
+            unsigned fl = 0xffffffffu;
+            if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
+            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+            __syncthreads();
         }
+        return;
+    }
+
+    // ---------------- gate waves ----------------
+    EpiIn ein[2];
+    int pend_ps = -1, pend_r = 0;    // round whose contraction is complete and whose gate math is due
+    auto finish = [&](int qlast) -> int {   // qlast: the g == 2 sub-iteration of the pending round; returns the group-C stores
+        int nstore = 0;
+        const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + lane * 16;
+        f32x4 a[2];
+#pragma unroll
+        for (int te = 0; te < 2; ++te) {
+            a[te] = *reinterpret_cast<const f32x4*>(xa + ((2 * hut) * 2 + te) * 1024);
+            a[te] += *reinterpret_cast<const f32x4*>(xa + ((2 * hut + 1) * 2 + te) * 1024);
+        }
+#pragma unroll
+        for (int te = 0; te < 2; ++te) nstore += epilogue(pend_ps, pend_r, te, ein[te], a[te]);
+        return nstore;
     };
     for (int q = q_begin; q < q_end; ++q) {
         const int ps = q / NQ, rem = q - ps * NQ;
         const int r = rem / 3, g = rem - 3 * r;
-        // the gate gradients stored during sub-iteration q - 1 (gate math of the round that ended at q - 2) were drained
-        // before the last barrier
-        if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
-            const int qp = q - 2;
-            const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
-            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (q + 1 < q_end) dma_sub(q + 1);
-        // gate math of the round that finished its contraction in the previous sub-iteration
-        if (g == 0 && pend_ps >= 0) { finish(q - 1); pend_ps = -1; }
-        // requests: inputs of this round's gate math, flags of the round after next
-        if (g == 1) {
+        if (g == 0) {
+            int younger = 0;                               // operations issued after the exchange stores (see cl_wait_vmcnt)
+            if (pend_ps >= 0) { younger += finish(q - 1); pend_ps = -1; }
+            CL_FENCE();
 #pragma unroll
-            for (int te = 0; te < NTE; ++te) epi_load(ps, r, te, ein[te]);
+            for (int te = 0; te < 2; ++te) younger += epi_load(ps, r, te, ein[te]);     // this round's inputs, used one round later
+            CL_FENCE();
+            cl_wait_vmcnt(younger);                        // exchange rows complete; outputs / inputs stay in flight
         }
-        const int q2 = q + 2;
-        const int ps2 = q2 / NQ, rem2 = q2 - ps2 * NQ;
-        const int r2 = rem2 / 3;
-        const bool do_poll = p.handoff && wave == 4 && q2 < q_end && rem2 % 3 == 0;
-        unsigned fl = 0xffffffffu;
-        if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g == 2) { pend_ps = ps; pend_r = r; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed, its stores are complete
-        if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
         __syncthreads();
     }
     if (pend_ps >= 0) finish(q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
@@ -859,7 +966,7 @@ int cl_mode() {
 ClPlan cl_plan(int B, int H, int ndir) {
     ClPlan pl;
     memset(&pl, 0, sizeof(pl));
-    if (cl_mode() == 0 || H <= 128 || H > 512 || (H % 4) != 0 || B < 128) return pl;
+    if (cl_mode() == 0 || H <= 256 || H > 512 || (H % 4) != 0 || B < 128) return pl;
     const int cus = cl_num_cus();
     pl.KSPLIT = H > 256 ? 2 : 1;
     pl.KP = 256 * pl.KSPLIT;
@@ -959,8 +1066,7 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
         return true;
     };
     bool ok;
-    if (pl.KSPLIT == 2) ok = bf ? launch(gru_cluster_fwd_kernel<2, true>, ClCfg<2, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<2, false>, ClCfg<2, false, 1>::LDS_BYTES);
-    else ok = bf ? launch(gru_cluster_fwd_kernel<1, true>, ClCfg<1, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<1, false>, ClCfg<1, false, 1>::LDS_BYTES);
+    ok = bf ? launch(gru_cluster_fwd_kernel<2, true>, ClCfg<2, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<2, false>, ClCfg<2, false, 1>::LDS_BYTES);
     if (!ok) { xps_set_error("gru cluster forward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
     XPS_CHECK_LAUNCH();
     return XPS_OK;
@@ -1011,8 +1117,7 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
         return true;
     };
     bool ok;
-    if (pl.KSPLIT == 2) ok = bf ? launch(gru_cluster_bwd_kernel<2, true>, ClCfg<2, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<2, false>, ClCfg<2, false, 3>::LDS_BYTES);
-    else ok = bf ? launch(gru_cluster_bwd_kernel<1, true>, ClCfg<1, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<1, false>, ClCfg<1, false, 3>::LDS_BYTES);
+    ok = bf ? launch(gru_cluster_bwd_kernel<2, true>, ClCfg<2, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<2, false>, ClCfg<2, false, 3>::LDS_BYTES);
     if (!ok) { xps_set_error("gru cluster backward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
     XPS_CHECK_LAUNCH();
     return XPS_OK;

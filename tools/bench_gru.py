@@ -34,9 +34,12 @@ for prec in precs:
     xf.set_gemm_precision(prec)
     for mode in modes:
         xf.set_gru_cluster_mode(mode)
+        xf.check_gru_status()
         f_tr = ev(lambda: xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True))
+        xf.check_gru_status()
         f_ev = ev(lambda: xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, False))
         y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
+        xf.check_gru_status()
         b_tr = ev(lambda: xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False))
         diag = ''
         if xf._gru_status_words:
