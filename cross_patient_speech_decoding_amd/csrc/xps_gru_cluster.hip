@@ -157,14 +157,20 @@ __device__ inline ClMap cl_map(int CS) {
     return m;
 }
 
-// one 1-KiB LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses (L1 bypassed: sc1) to LDS [lds_dst, +1024).
-// Inline asm: with the builtin the compiler orders EVERY later LDS read of the wave behind the piece with vmcnt(0).  Only
-// the two mover waves issue pieces; apart from them they issue flag stores / polls, and they drain with vmcnt(0) before the
-// round's barrier.  M0 is saved and restored (compiler-reserved).
-__device__ inline void cl_dma_piece(const unsigned char* gsrc, unsigned lds_dst) {
+// Four 1-KiB LDS-DMA pieces: each moves 64 lanes x 16 B from per-lane global addresses (gsrc, + 1024, + 2048, + 3072;
+// L1 bypassed: sc1) to LDS [M0 + the same immediate, + 1024): the pads of the LDS image are folded into the M0 values.
+// Inline asm: with the builtin the compiler orders EVERY later LDS read of the wave behind a piece with vmcnt(0).  Only the
+// contraction waves issue pieces; they issue no other vector-memory operation in their loop and drain with vmcnt(0) before
+// the round's barrier.  M0 is saved and restored (compiler-reserved).
+__device__ inline void cl_dma4(const unsigned char* gsrc, unsigned l0, unsigned l1, unsigned l2, unsigned l3) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst));
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1024 sc1\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:2048 sc1\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:3072 sc1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(l0), "s"(l1), "s"(l2), "s"(l3));
 }
 
 __device__ inline unsigned cl_lds_base(const unsigned char* smem) {
@@ -248,16 +254,15 @@ struct ClFwd {
     int s_begin, s_end, handoff;
 };
 
-// 512 threads, three kinds of waves (every SIMD holds a contraction wave and one of the others, so the matrix pipe never
-// waits for a vector-memory issue slot, a memory latency or the gate math):
-//   waves 0-3  CONTRACT: resident W_hh fragments (unit tile ut = w / 2, k-half kh = w % 2), LDS operand reads, MFMA, products to
-//              xacc; nothing else;
-//   waves 4-5  MOVE: the LDS-DMA pieces of the next round's operand (32 each), the flags (wave 4); they drain with vmcnt(0)
-//              (only L2-served operations are ever in flight there);
-//   waves 6-7  GATES (unit tile w - 6, both trial tiles): sum the two k-halves from xacc, gate math, exchange rows, outputs,
-//              requests for the gate inputs of later rounds.  Their vector-memory operations are all visible to the compiler
-//              (its waits for the input loads are exact) and only the exchange rows must be complete at the barrier
-//              (cl_wait_vmcnt): output stores and input loads stay in flight across rounds.
+// 512 threads, two kinds of waves; every SIMD holds one of each, so the matrix pipe never waits for a memory latency or for
+// the gate math:
+//   waves 0-3  CONTRACT: resident W_hh fragments (unit tile ut = w / 2, k-half kh = w % 2), LDS operand reads, MFMA, products
+//              to xacc, and between the MFMA chunks their quarter of the LDS-DMA pieces of the NEXT round's operand (the only
+//              vector-memory operations they issue: drained with vmcnt(0) before the barrier);
+//   waves 4-7  GATES: wave 4 + h owns (unit tile h / 2, trial tile h % 2): sum of the two k-halves from xacc, gate math,
+//              exchange rows, outputs, requests for the gate inputs of later rounds, flags (wave 4).  All their vector-memory
+//              operations are visible to the compiler (its waits for the input loads are exact) and only the exchange rows
+//              must be complete at the barrier (cl_wait_vmcnt): output stores and input loads stay in flight across rounds.
 // Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster); one barrier per round.  During round it: contraction of
 // round it (buffer it & 1), pieces of round it + 1 into the other buffer, gate math of round it - 1, flag of round it - 2
 // (its exchange rows were complete before the last barrier), poll of the flags of round it + 2.
@@ -265,10 +270,10 @@ template <int KSPLIT, bool BF>
 __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     static_assert(KSPLIT == 2, "the cluster kernels cover 256 < H <= 512");
     using Cf = ClCfg<KSPLIT, BF, 1>;
-    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 2;
+    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xacc = smem + 2 * TILE;
-    unsigned* consumed = reinterpret_cast<unsigned*>(xacc + Cf::XACC_BYTES);      // [2] rounds taken out of xacc, per gate wave
+    unsigned* consumed = reinterpret_cast<unsigned*>(xacc + Cf::XACC_BYTES);      // [4] rounds taken out of xacc, per gate wave
     const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,26 +285,28 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     const int m_base = blk * p.Mc;
     const int it_begin = p.s_begin * NR, it_end = p.s_end * NR;
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
-    if (tid < 2) consumed[tid] = 0u;
+    if (tid < 4) consumed[tid] = 0u;
 
     // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
     const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
 
-    // a mover wave's half of round itn's operand: PPW pieces -> buffer itn & 1
+    // contraction wave w moves pieces [16 w, 16 w + 16) of a round (trials 8 w .. 8 w + 7 of the 32) in four groups of four
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
-    auto dma_round = [&](int itn) {
-        const int mv = wave - 4;
-        const int sn = itn / NR, rn = itn - sn * NR;
-        const unsigned char* src = xb + (size_t)(((sn & 1) * p.ndir + dir) * p.Bp + m_base + 32 * rn) * (KP * 4) + (size_t)(mv * PPW) * 1024 + lane * 16;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            // piece index mv * PPW + i; PPW is even, so the plane / half of a piece is that of i
-            const unsigned dst = lds0 + (unsigned)((itn & 1) * TILE) + (unsigned)(((mv * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024));
-            cl_dma_piece(src + i * 1024, dst);
-        }
+    auto dma_src = [&](int s_, int r_) -> const unsigned char* {
+        return xb + (size_t)(((s_ & 1) * p.ndir + dir) * p.Bp + m_base + 32 * r_) * (KP * 4) + (size_t)(wave * 16) * 1024 + lane * 16;
     };
-    if (wave == 4 || wave == 5) {
-        dma_round(it_begin);
+    auto dma_group = [&](const unsigned char* src, int buf, int grp) {      // grp = 0 .. 3 (compile time at every call site)
+        const int j = wave * 16 + grp * 4;                                  // first piece: a multiple of four = trial boundary
+        const unsigned base = lds0 + (unsigned)(buf * TILE) + (unsigned)((j >> 1) * TS);
+        // pieces j .. j + 3 = (trial, half) (t, 0), (t, 1), (t + 1, 0), (t + 1, 1); the immediates add 0, 1024, 2048, 3072
+        const unsigned h = BF ? PS : 1024;
+        cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
+    };
+
+    if (wave < 4) {
+        const unsigned char* src = dma_src(p.s_begin, 0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dma_group(src, it_begin & 1, g4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -327,8 +334,12 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             w.load(seg, rlive, kq, H - kbase, W);
         }
         CL_STAMP(sb2)
+        int s_nx = p.s_begin, r_nx = 1;                 // (step, round) of iteration it + 1
+        if (r_nx == NR) { r_nx = 0; ++s_nx; }
         for (int it = it_begin; it < it_end; ++it) {
             const unsigned char* tb = smem + (it & 1) * TILE;
+            const bool has_next = it + 1 < it_end;
+            const unsigned char* src = dma_src(s_nx, r_nx);
             f32x4 acc[2][3];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
                 if constexpr (BF) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
+                        if (has_next && (c & 3) == 0) dma_group(src, (it + 1) & 1, tt * 2 + (c >> 2));
                         const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
                         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
@@ -350,6 +362,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
                 } else {
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
+                        if (has_next && (c & 7) == 0) dma_group(src, (it + 1) & 1, tt * 2 + (c >> 3));
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -362,44 +375,18 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             // the previous round's products must have been taken out of xacc (they were, two thousand cycles ago: one look)
             if (it > it_begin) {
                 const unsigned want = (unsigned)(it - it_begin);
-                while (__hip_atomic_load(consumed + ut, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(consumed + 2 * ut, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
+                       __hip_atomic_load(consumed + 2 * ut + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+                    __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
                     *reinterpret_cast<f32x4*>(xacc + ((wave * 2 + tt) * 3 + g) * 1024 + lane * 16) = acc[tt][g];
-            CL_STAMP(sb0)
-            __syncthreads();
-            CL_STAMP(sb1)
-            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb0)
-#ifdef XPS_CL_STAMP
-            sb2 = sb1;
-#endif
-        }
-        CL_STORE_STAMPS()
-        return;
-    }
-
-    if (wave < 6) {
-        // ---------------- mover waves ----------------
-        for (int it = it_begin; it < it_end; ++it) {
-            // flag of round it - 2: the gate waves stored its exchange rows during round it - 1 and had them complete before
-            // the last barrier
-            if (p.handoff && wave == 4 && lane == 0 && it >= it_begin + 2) {
-                const int itp = it - 2;
-                const int sp = itp / NR, rp = itp - sp * NR;
-                __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (it + 1 < it_end) dma_round(it + 1);
-            const int it2 = it + 2;
-            const int s2 = it2 / NR, r2 = it2 - s2 * NR;
-            const bool do_poll = p.handoff && wave == 4 && it2 < it_end && s2 > p.s_begin;
-            unsigned fl = 0xffffffffu;
-            if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++r_nx == NR) { r_nx = 0; ++s_nx; }
             CL_STAMP(sb3)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
-            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)s2, p.CS, lane, fl, p.status);
             CL_STAMP(sb0)
             __syncthreads();
             CL_STAMP(sb1)
@@ -413,7 +400,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     }
 
     // ---------------- gate waves ----------------
-    const int hut = wave - 6;                          // unit tile
+    const int hw = wave - 4;
+    const int hut = hw >> 1, te = hw & 1;              // unit tile, trial tile of the round
     const int j0 = cm.member * Cf::U + hut * 16;
     const int ju = j0 + 4 * kq;                        // this lane's four units
     const bool ulive = ju < H;
@@ -430,8 +418,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         if (!ulive) bias[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     struct EpiIn { f32x4 gr, gz, gn; u32x4 hp; };
-    auto epi_load = [&](int itn, int te, EpiIn& in) {      // 4 loads, always issued
-        const int sn = itn / NR, rn = itn - sn * NR;
+    auto epi_load = [&](int sn, int rn, EpiIn& in) {      // 4 loads, always issued
         const int t = (dir == 0) ? sn : T - 1 - sn;
         const int slot_prev = (dir == 0) ? t : t + 2;
         const int b = m_base + 32 * rn + 16 * te + n;
@@ -443,108 +430,105 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         // own previous state (fp32), written by this lane one step ago (or by the init kernel)
         in.hp = __builtin_amdgcn_raw_buffer_load_b128(yr, (unsigned)((((long long)slot_prev * B + bc) * ldy + dir * H + juc) * 4), 0, AUX_SC1);
     };
-    // gates + hidden update of round itn for this lane's trial and four units; a_* = complete pre-activation products
-    struct EpiOut { f32x4 o, rg, zg, ng, qv; };
-    auto epi_compute = [&](int itn, int te, const EpiIn& in, f32x4 a_r, f32x4 a_z, f32x4 a_n, EpiOut& out) {
-        const int sn = itn / NR, rn = itn - sn * NR;
-        const int b = m_base + 32 * rn + 16 * te + n;
-        const bool live = b < B && ulive;
-        const f32x4 hp = __builtin_bit_cast(f32x4, in.hp);      // (whole vector: a bit_cast of ONE element reads element 0)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            out.rg[i] = cl_sigmoid(in.gr[i] + a_r[i] + bias[0][i]);
-            out.zg[i] = cl_sigmoid(in.gz[i] + a_z[i] + bias[1][i]);
-            out.qv[i] = a_n[i] + bias[2][i];
-            out.ng[i] = cl_tanh(in.gn[i] + out.rg[i] * out.qv[i]);
-            out.o[i] = live ? out.ng[i] + out.zg[i] * (hp[i] - out.ng[i]) : 0.f;
-        }
-    };
-    // exchange rows of the next step (every lane stores: rows of pad trials / pad units carry zeros)
-    auto epi_exchange = [&](int itn, int te, const EpiOut& out) {
-        const int sn = itn / NR, rn = itn - sn * NR;
-        if (sn + 1 >= T) return;
-        const int b = m_base + 32 * rn + 16 * te + n;
-        const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
-        if constexpr (BF) {
-            bf16x4 sh, sl;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split(out.o[i], a, c); sh[i] = a; sl[i] = c; }
-            const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
-            if (fast) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
-            }
-        } else {
-            const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
-            if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.o), xr, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.o), xr, off, 0, AUX_SC1);
-        }
-    };
-    // outputs: h_t and (training) the saved gates; 1 or 5 stores, ALWAYS issued (dead lanes: offset out of range, dropped)
-    auto epi_outputs = [&](int itn, int te, const EpiOut& out) {
-        const int sn = itn / NR, rn = itn - sn * NR;
+    // gates + hidden update of round (sn, rn) for this lane's trial and four units; exchange rows of the next step (every lane
+    // stores: rows of pad trials / pad units carry zeros), then the outputs: h_t and (training) the saved gates, 1 or 5 stores,
+    // ALWAYS issued (dead lanes: offset out of range, dropped)
+    auto epilogue = [&](int sn, int rn, const EpiIn& in, const f32x4 (&a)[3]) {
         const int t = (dir == 0) ? sn : T - 1 - sn;
         const int b = m_base + 32 * rn + 16 * te + n;
         const bool live = b < B && ulive;
+        const f32x4 hp = __builtin_bit_cast(f32x4, in.hp);      // (whole vector: a bit_cast of ONE element reads element 0)
+        f32x4 o, rg, zg, ng, qv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rg[i] = cl_sigmoid(in.gr[i] + a[0][i] + bias[0][i]);
+            zg[i] = cl_sigmoid(in.gz[i] + a[1][i] + bias[1][i]);
+            qv[i] = a[2][i] + bias[2][i];
+            ng[i] = cl_tanh(in.gn[i] + rg[i] * qv[i]);
+            o[i] = live ? ng[i] + zg[i] * (hp[i] - ng[i]) : 0.f;
+        }
+        CL_FENCE();
+        if (sn + 1 < T) {
+            const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
+            if constexpr (BF) {
+                bf16x4 sh, sl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __bf16 x, c; bf_split(o[i], x, c); sh[i] = x; sl[i] = c; }
+                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
+                if (fast) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                }
+            } else {
+                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
+                if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, off, 0, AUX_SC1);
+            }
+        }
+        CL_FENCE();
         const unsigned yo = live ? (unsigned)((((long long)(t + 1) * B + b) * ldy + dir * H + ju) * 4) : CL_OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.o), yr, yo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, yo, 0, 0);
         if (has_saved) {
             const unsigned so = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 4 * H + ju) * 4) : CL_OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.rg), sr, so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.zg), sr, live ? so + (unsigned)H * 4u : CL_OOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.ng), sr, live ? so + (unsigned)H * 8u : CL_OOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out.qv), sr, live ? so + (unsigned)H * 12u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rg), sr, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zg), sr, live ? so + (unsigned)H * 4u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ng), sr, live ? so + (unsigned)H * 8u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), sr, live ? so + (unsigned)H * 12u : CL_OOB, 0, 0);
         }
     };
-    // products of the finished round for both trial tiles: k-low half + k-high half, taken out of xacc
-    f32x4 prod[2][3];
+    // products of the finished round for this wave's trial tile: k-low half + k-high half, taken out of xacc
+    f32x4 prod[3];
     auto take_products = [&](int rounds_done) {
 #pragma unroll
-        for (int te = 0; te < 2; ++te)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut) * 2 + te) * 3 + g) * 1024 + lane * 16);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut + 1) * 2 + te) * 3 + g) * 1024 + lane * 16);
-                prod[te][g] = lo + hi;
-            }
+        for (int g = 0; g < 3; ++g) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut) * 2 + te) * 3 + g) * 1024 + lane * 16);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut + 1) * 2 + te) * 3 + g) * 1024 + lane * 16);
+            prod[g] = lo + hi;
+        }
         // the reads above must have returned before the contraction waves may overwrite xacc
-        if (lane == 0) __hip_atomic_store(consumed + hut, (unsigned)rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(consumed + hw, (unsigned)rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     // gate inputs live in two register slots (round parity relative to the launch's first round): requested during round
     // it - 1, used during round it + 1.  The loop body is instantiated per slot so that no copy (which would wait for the
-    // loads) and no dynamic register index is needed.
-    EpiIn ein[2][2];
-#pragma unroll
-    for (int te = 0; te < 2; ++te) epi_load(it_begin, te, ein[0][te]);
+    // loads) and no dynamic register index is needed.  (step, round) of rounds it - 1, it + 1, it + 2 are carried along.
+    EpiIn ein[2];
+    epi_load(p.s_begin, 0, ein[0]);
+    int s_pv = p.s_begin, r_pv = -1;                    // round it - 1
+    int s_nx = p.s_begin, r_nx = 1;                     // round it + 1
+    if (r_nx == NR) { r_nx = 0; ++s_nx; }
+    int s_n2 = s_nx, r_n2 = r_nx + 1;                   // round it + 2
+    if (r_n2 == NR) { r_n2 = 0; ++s_n2; }
     auto round_body = [&](int it, auto SLOT) {
         constexpr int cur = decltype(SLOT)::value;            // slot of round it (and of round it + 2); round it - 1 / it + 1: the other
+        // oldest group: flag of round it - 2 (its exchange rows were complete before the last barrier), flags of round it + 2
+        if (p.handoff && wave == 4 && lane == 0 && it >= it_begin + 2) {
+            int rp = r_pv - 1, sp = s_pv;
+            if (rp < 0) { rp = NR - 1; --sp; }
+            __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(sp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool do_poll = p.handoff && wave == 4 && it + 2 < it_end && s_n2 > p.s_begin;
+        unsigned fl = 0xffffffffu;
+        if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r_n2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CL_FENCE();
         int younger = 0;                                    // operations issued after the exchange stores (see cl_wait_vmcnt)
         if (it > it_begin) {
             take_products(it - it_begin);
-            EpiOut out[2];
-#pragma unroll
-            for (int te = 0; te < 2; ++te) epi_compute(it - 1, te, ein[cur ^ 1][te], prod[te][0], prod[te][1], prod[te][2], out[te]);
-            CL_FENCE();
-#pragma unroll
-            for (int te = 0; te < 2; ++te) epi_exchange(it - 1, te, out[te]);
-            CL_FENCE();
-#pragma unroll
-            for (int te = 0; te < 2; ++te) epi_outputs(it - 1, te, out[te]);
-            younger += 2 * (has_saved ? 5 : 1);
+            epilogue(s_pv, r_pv, ein[cur ^ 1], prod);
+            younger += has_saved ? 5 : 1;
         }
         CL_FENCE();
         if (it + 1 < it_end) {
-#pragma unroll
-            for (int te = 0; te < 2; ++te) epi_load(it + 1, te, ein[cur ^ 1][te]);
-            younger += 2 * 4;
+            epi_load(s_nx, r_nx, ein[cur ^ 1]);
+            younger += 4;
         }
         CL_FENCE();
         CL_STAMP(sb3)
         cl_wait_vmcnt(younger);                             // exchange rows complete; outputs / next inputs stay in flight
+        if (do_poll) cl_wait(myflags + r_n2 * 16, (unsigned)s_n2, p.CS, lane, fl, p.status);
         CL_STAMP(sb0)
         __syncthreads();
         CL_STAMP(sb1)
@@ -552,6 +536,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
 #ifdef XPS_CL_STAMP
         sb2 = sb1;
 #endif
+        if (++r_pv == NR) { r_pv = 0; ++s_pv; }
+        if (++r_nx == NR) { r_nx = 0; ++s_nx; }
+        if (++r_n2 == NR) { r_n2 = 0; ++s_n2; }
     };
     for (int it = it_begin; it < it_end; it += 2) {
         round_body(it, std::integral_constant<int, 0>{});
@@ -559,15 +546,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     }
     if (it_end > it_begin) {                                    // (outputs of the launch's last round; nobody waits for its flag)
         take_products(it_end - it_begin);
-        EpiOut out[2];
         const bool odd = ((it_end - 1 - it_begin) & 1) != 0;
-#pragma unroll
-        for (int te = 0; te < 2; ++te) {
-            if (odd) epi_compute(it_end - 1, te, ein[1][te], prod[te][0], prod[te][1], prod[te][2], out[te]);
-            else epi_compute(it_end - 1, te, ein[0][te], prod[te][0], prod[te][1], prod[te][2], out[te]);
-            epi_exchange(it_end - 1, te, out[te]);
-            epi_outputs(it_end - 1, te, out[te]);
-        }
+        if (odd) epilogue(s_pv, r_pv, ein[1], prod);
+        else epilogue(s_pv, r_pv, ein[0], prod);
     }
     CL_STORE_STAMPS()
 }
@@ -630,16 +611,16 @@ struct ClBwd {
     int ps_begin, ps_end, ps_total, handoff;
 };
 
-// Same three wave roles as the forward kernel.  Sub-iteration q = (ps, round r, gate segment g): contraction waves
-// accumulate segment g of round r (buffer q & 1) and hand the finished products over after g == 2 (xacc, double buffered by
-// round parity); movers stream sub-iteration q + 1; gate waves act once per round, during its first sub-iteration: gate
-// math of the PREVIOUS round (products from xacc, inputs requested one round earlier), exchange rows, outputs, then the
-// requests for THIS round's inputs.
+// Same two wave roles as the forward kernel.  Sub-iteration q = (ps, round r, gate segment g): contraction waves accumulate
+// segment g of round r (buffer q & 1), stream their quarter of sub-iteration q + 1's operand between the MFMA chunks and hand
+// the finished products over after g == 2 (xacc, double buffered by round parity); gate waves act once per round, during its
+// first sub-iteration: gate math of the PREVIOUS round (products from xacc, inputs requested one round earlier), exchange rows,
+// outputs, then the requests for THIS round's inputs; wave 4 also keeps the flags.
 template <int KSPLIT, bool BF>
 __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     static_assert(KSPLIT == 2, "the cluster kernels cover 256 < H <= 512");
     using Cf = ClCfg<KSPLIT, BF, 3>;
-    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES, PPW = Cf::NPIECE / 2;
+    constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xacc = smem + 2 * TILE;              // [round parity 2][contraction wave 4][tile 2] x 1 KiB
     const unsigned lds0 = cl_lds_base(smem);
@@ -655,8 +636,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
     const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
 
-    // gate waves: unit tile, units, buffers
-    const int hut = wave >= 6 ? wave - 6 : 0;
+    // gate waves: unit tile, trial tile, units, buffers
+    const int hw = wave >= 4 ? wave - 4 : 0;
+    const int hut = hw >> 1, te = hw & 1;
     const int ju = cm.member * Cf::U + hut * 16 + 4 * kq;
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
@@ -667,23 +649,23 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
     const bool has_dy = p.dy != nullptr;
 
-    // sub-iteration q = ps * NQ + r * 3 + g reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1)
+    // sub-iteration (ps, r, g) reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1); contraction
+    // wave w moves pieces [16 w, 16 w + 16) in four groups of four
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
-    auto dma_sub = [&](int qn) {
-        const int mv = wave - 4;
-        const int psn = qn / NQ, rem = qn - psn * NQ;
-        const size_t chunk = (size_t)(((((psn - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + rem / 3) * 3 + rem % 3);
-        const unsigned char* src = xb + chunk * Cf::CHUNK_BYTES + (size_t)(mv * PPW) * 1024 + lane * 16;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const unsigned dst = lds0 + (unsigned)((qn & 1) * TILE) + (unsigned)(((mv * PPW + i) >> 1) * TS + (i & 1) * (BF ? PS : 1024));
-            cl_dma_piece(src + i * 1024, dst);
-        }
+    auto dma_src = [&](int ps_, int r_, int g_) -> const unsigned char* {
+        const size_t chunk = (size_t)(((((ps_ - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r_) * 3 + g_);
+        return xb + chunk * Cf::CHUNK_BYTES + (size_t)(wave * 16) * 1024 + lane * 16;
+    };
+    auto dma_group = [&](const unsigned char* src, int buf, int grp) {
+        const int j = wave * 16 + grp * 4;
+        const unsigned base = lds0 + (unsigned)(buf * TILE) + (unsigned)((j >> 1) * TS);
+        const unsigned h = BF ? PS : 1024;
+        cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
     };
 
     struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
-    // inputs of the gate math of (ps, r), trial tile te: returns the number of loads issued (always the same for a given ps)
-    auto epi_load = [&](int ps, int r, int te, EpiIn& in) -> int {
+    // inputs of the gate math of (ps, r): returns the number of loads issued (always the same for a given ps)
+    auto epi_load = [&](int ps, int r, EpiIn& in) -> int {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
         const int slot_prev = (dir == 0) ? t : t + 2;
@@ -709,10 +691,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         }
         return nload;
     };
-    // gate gradients of processing step ps for (round r, tile te, this lane's trial and units); acc = dgh_{ps-1} W_hh (own units).
+    // gate gradients of processing step ps for (round r, this lane's trial and units); acc = dgh_{ps-1} W_hh (own units).
     // Stores: the exchange rows first (group B), then the outputs (group C, always issued: dead lanes are dropped by the range
     // check); returns the number of group-C stores.
-    auto epilogue = [&](int ps, int r, int te, const EpiIn& in, const f32x4& acc) -> int {
+    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) -> int {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
         const int b = m_base + 32 * r + 16 * te + n;
@@ -774,14 +756,11 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     int ps0 = p.ps_begin;
     if (ps0 == 0) {
         // first processing step: no contraction, the running gradient starts from dhn (or zero); gate waves only
-        if (wave >= 6) {
+        if (wave >= 4) {
             for (int r = 0; r < NR; ++r) {
-#pragma unroll
-                for (int te = 0; te < 2; ++te) {
-                    EpiIn in;
-                    epi_load(0, r, te, in);
-                    epilogue(0, r, te, in, (f32x4){0.f, 0.f, 0.f, 0.f});
-                }
+                EpiIn in;
+                epi_load(0, r, in);
+                epilogue(0, r, in, (f32x4){0.f, 0.f, 0.f, 0.f});
             }
         }
         ps0 = 1;
@@ -801,8 +780,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         cl_wait(myflags, (unsigned)ps0, p.CS, lane, f0, p.status);
     }
     __syncthreads();
-    if (wave == 4 || wave == 5) {
-        dma_sub(q_begin);
+    if (wave < 4) {
+        const unsigned char* src = dma_src(ps0, 0, 0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dma_group(src, q_begin & 1, g4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -822,9 +803,12 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             w.load(seg, rlive, kq, H - kbase, WT);
         }
         f32x4 acc[2];
+        int ps = ps0, r = 0, g = 0;                      // (ps, r, g) of sub-iteration q
         for (int q = q_begin; q < q_end; ++q) {
-            const int ps = q / NQ, rem = q - ps * NQ;
-            const int r = rem / 3, g = rem - 3 * r;
+            int ps_n = ps, r_n = r, g_n = g + 1;         // sub-iteration q + 1
+            if (g_n == 3) { g_n = 0; if (++r_n == NR) { r_n = 0; ++ps_n; } }
+            const bool has_next = q + 1 < q_end;
+            const unsigned char* src = dma_src(ps_n, r_n, g_n);
             if (g == 0) {
                 acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 acc[1] = acc[0];
@@ -838,6 +822,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                     if constexpr (BF) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
+                            if (has_next && (c & 3) == 0) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
                             const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
                             const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
@@ -848,6 +833,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                     } else {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
+                            if (has_next && (c & 7) == 0) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 3));
                             const f32x4 a4 = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -866,67 +852,52 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                 *reinterpret_cast<f32x4*>(xw) = acc[0];
                 *reinterpret_cast<f32x4*>(xw + 1024) = acc[1];
             }
-            __syncthreads();
-        }
-        return;
-    }
-
-    if (wave < 6) {
-        // ---------------- mover waves ----------------
-        for (int q = q_begin; q < q_end; ++q) {
-            const int rem = q % NQ;
-            const int g = rem % 3;
-            // the gate waves stored the exchange rows of the round that ended at q - 2 during sub-iteration q - 1 and had them
-            // complete before the last barrier
-            if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
-                const int qp = q - 2;
-                const int psp = qp / NQ, rp = (qp - psp * NQ) / 3;
-                __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (q + 1 < q_end) dma_sub(q + 1);
-            const int q2 = q + 2;
-            const int ps2 = q2 / NQ, rem2 = q2 - ps2 * NQ;
-            const int r2 = rem2 / 3;
-            const bool do_poll = p.handoff && wave == 4 && q2 < q_end && rem2 % 3 == 0;
-            unsigned fl = 0xffffffffu;
-            if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ps = ps_n; r = r_n; g = g_n;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
-            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
             __syncthreads();
         }
         return;
     }
 
     // ---------------- gate waves ----------------
-    EpiIn ein[2];
+    EpiIn ein;
     int pend_ps = -1, pend_r = 0;    // round whose contraction is complete and whose gate math is due
     auto finish = [&](int qlast) -> int {   // qlast: the g == 2 sub-iteration of the pending round; returns the group-C stores
-        int nstore = 0;
         const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + lane * 16;
-        f32x4 a[2];
-#pragma unroll
-        for (int te = 0; te < 2; ++te) {
-            a[te] = *reinterpret_cast<const f32x4*>(xa + ((2 * hut) * 2 + te) * 1024);
-            a[te] += *reinterpret_cast<const f32x4*>(xa + ((2 * hut + 1) * 2 + te) * 1024);
-        }
-#pragma unroll
-        for (int te = 0; te < 2; ++te) nstore += epilogue(pend_ps, pend_r, te, ein[te], a[te]);
-        return nstore;
+        f32x4 a = *reinterpret_cast<const f32x4*>(xa + ((2 * hut) * 2 + te) * 1024);
+        a += *reinterpret_cast<const f32x4*>(xa + ((2 * hut + 1) * 2 + te) * 1024);
+        return epilogue(pend_ps, pend_r, ein, a);
     };
-    for (int q = q_begin; q < q_end; ++q) {
-        const int ps = q / NQ, rem = q - ps * NQ;
-        const int r = rem / 3, g = rem - 3 * r;
-        if (g == 0) {
-            int younger = 0;                               // operations issued after the exchange stores (see cl_wait_vmcnt)
-            if (pend_ps >= 0) { younger += finish(q - 1); pend_ps = -1; }
-            CL_FENCE();
-#pragma unroll
-            for (int te = 0; te < 2; ++te) younger += epi_load(ps, r, te, ein[te]);     // this round's inputs, used one round later
-            CL_FENCE();
-            cl_wait_vmcnt(younger);                        // exchange rows complete; outputs / inputs stay in flight
+    {
+        int ps = ps0, r = 0, g = 0;
+        for (int q = q_begin; q < q_end; ++q) {
+            // flag of the round that ended at q - 2: its exchange rows were stored during sub-iteration q - 1 and complete before
+            // the last barrier
+            if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
+                int rp = r - 1, psp = ps;
+                if (rp < 0) { rp = NR - 1; --psp; }
+                __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // flags of the round whose first sub-iteration is q + 2 (only when g == 1: q + 2 = (next round, 0))
+            int r2 = r + 1, ps2 = ps;
+            if (r2 == NR) { r2 = 0; ++ps2; }
+            const bool do_poll = p.handoff && wave == 4 && g == 1 && q + 2 < q_end;
+            unsigned fl = 0xffffffffu;
+            if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == 0) {
+                CL_FENCE();
+                int younger = 0;                               // operations issued after the exchange stores (see cl_wait_vmcnt)
+                if (pend_ps >= 0) { younger += finish(q - 1); pend_ps = -1; }
+                CL_FENCE();
+                younger += epi_load(ps, r, ein);               // this round's inputs, used one round later
+                CL_FENCE();
+                cl_wait_vmcnt(younger);                        // exchange rows complete; outputs / inputs stay in flight
+            }
+            if (g == 2) { pend_ps = ps; pend_r = r; }
+            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+            __syncthreads();
+            if (++g == 3) { g = 0; if (++r == NR) { r = 0; ++ps; } }
         }
-        if (g == 2) { pend_ps = ps; pend_r = r; }
-        __syncthreads();
     }
     if (pend_ps >= 0) finish(q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
 }

@@ -23,6 +23,6 @@ for save in (True, False):
     raw = np.array(buf[:], dtype=np.float64).reshape(2048, 8)
     rounds = T * 8
     print('forward, saving gates' if save else 'forward, eval', '- cycles per round (median over workgroups): work / drain / barrier wait')
-    for role, ws_ in (('contraction', [0, 1, 2, 3]), ('mover', [4, 5]), ('gates', [6, 7])):
+    for role, ws_ in (('contraction', [0, 1, 2, 3]), ('gates', [4, 5, 6, 7])):
         sel = np.concatenate([raw[w::8] for w in ws_])
         print(f'   {role:12s} {np.median(sel[:, 0]) / rounds:8.0f} {np.median(sel[:, 1]) / rounds:8.0f} {np.median(sel[:, 2]) / rounds:8.0f}')
