@@ -61,32 +61,41 @@ def build_model(c, dropout=0.3):
                       activation=False, decay_iters=500)
 
 
-def cpu_baseline(c, budget_s=20.0):
-    """The CPU oracle (plain torch.nn restatement of the reference, pinned to reference goldens) on
-    the same workload, bounded: B = 256 trials per step, as many steps as fit the budget."""
+def cpu_baseline(c):
+    """The CPU oracle (plain torch.nn restatement of the reference, pinned to reference goldens) on the SAME workload:
+    the full batch of 2048 trials per step (the reference trains full-batch), fp32, forward + backward + clip + AdamW.
+    All cores of the GPU's host share (at most 16: oversubscribed small GEMMs run slower): 3 warm-up + 10 timed steps,
+    median; and ONE thread: 1 warm-up + 3 timed steps, median (a bounded sample: a step takes seconds there)."""
     from oracle.seq2seq_oracle import Seq2SeqOracle, train_step
-    # the GPU box exposes far more logical CPUs than it may use (16-core share per GPU): oversubscribed
-    # small GEMMs run SLOWER, so the baseline uses at most 16 threads
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = Seq2SeqOracle(c['in_channels'], c['n_filters'], c['hidden_size'], c['num_classes'], c['n_enc_layers'],
                       c['n_dec_layers'], c['kernel_size'], c['stride'], 0, 0.3, 0.3, learning_rate=1e-4,
                       l2_reg=1e-5, activation=False, decay_iters=500)
     opt, _ = m.make_optimizer()
-    X, y = make_data(0, dict(c, trials_per_gpu=256))
-    for _ in range(2):
-        train_step(m, opt, X, y, coins=[True, False, True])
-    n, t0 = 0, time.perf_counter()
-    while True:
-        train_step(m, opt, X, y, coins=[True, False, True])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
-            break
-    return {'value': round(256 * n / el, 1), 'unit': 'trials/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} full train steps (fwd+bwd+clip+AdamW) of B=256 trials, same architecture/T/C, '
-                      f'fp32 torch.nn CPU oracle, {threads} threads, {el:.1f} s'}
+    X, y = make_data(0, c)
+    B = X.shape[0]
+
+    def run(threads, warm, timed):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            train_step(m, opt, X, y, coins=[True, False, True])
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            train_step(m, opt, X, y, coins=[True, False, True])
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], sum(ts)
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    med_all, _ = run(threads, 3, 10)
+    med_one, _ = run(1, 1, 3)
+    el = time.perf_counter() - t0
+    return {'value': round(B / med_all, 1), 'unit': 'trials/s', 'cores': threads, 'kind': 'port',
+            'sample': f'full batch of {B} trials per step (fwd+bwd+clip+AdamW), same architecture/T/C, fp32 torch.nn CPU oracle: '
+                      f'{threads} threads, 3 warm-up + 10 timed steps, median {med_all * 1e3:.0f} ms/step; whole baseline {el:.0f} s',
+            'one_thread': {'value': round(B / med_one, 1), 'unit': 'trials/s', 'cores': 1,
+                           'sample': f'1 warm-up + 3 timed steps, median {med_one * 1e3:.0f} ms/step'}}
 
 
 def _event_time(fn, iters=20, warm=3):
@@ -216,12 +225,102 @@ def time_dominant_kernel(model, c, captured=None):
     return out
 
 
+def _timed_steps(step, steps, warm):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _make_step(c, dev, rank, dropout=0.3):
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    torch.manual_seed(1234)
+    model = build_model(c, dropout).to(dev)
+    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5)
+    X, y = make_data(rank, c)
+    X, y = X.to(dev), y.to(dev)
+    model.train()
+    one = torch.ones((), device=dev)
+
+    def step():
+        opt.zero_grad()
+        logits = model(X, y, teacher_forcing_ratio=0.5)
+        loss = model.criterion(logits.view(-1, c['num_classes']), y.view(-1))
+        loss.backward(one)
+        opt.step()
+        return loss
+    return model, step
+
+
+def north_star_shard(dev, steps=10, warm=10):
+    """Second record: the per-GPU shard of configs[3] (8-patient MCCA + bidirectional 2-layer GRU, H = 512, on 8 GPUs): 2048
+    trials per GPU and step of the aligned d = 30 latent input, F = 100, k = s = 10 (T' = 20), enc 2 x bi-GRU H = 512, dec
+    1 x GRU.  Same step function as the headline (dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW), single GPU, no
+    collective; the recurrence runs the cluster-persistent kernels (csrc/xps_gru_cluster.hip), timed alone beside it."""
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    c = dict(CFG, in_channels=30, hidden_size=512)
+    model, step = _make_step(c, dev, 0)
+    dt = _timed_steps(step, steps, warm)
+    XF.check_gru_status()
+    fl = train_flops_per_trial(c)
+    B, H, Tp = c['trials_per_gpu'], 512, 20
+    rnn = model.encoder.rnn
+    w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
+    b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
+    gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
+    dy = torch.randn(Tp, B, 2 * H, device=dev) * 0.1
+    t_f = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True), iters=10)
+    y_ext, saved = XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True)
+    t_b = _event_time(lambda: XF._gru_backward(dy, None, y_ext, saved, w_hh, Tp, B, H, 2, False), iters=10)
+    XF.check_gru_status()
+    by_f = 4 * 2 * Tp * B * (3 * H + H + 4 * H)              # gi in, h + saved gates (r, z, n, q) out
+    by_b = 4 * 2 * Tp * B * (4 * H + H + H + 3 * H + H)      # saved gates, dy, h_prev in; dgi, dghn out
+    fl_rec = 2.0 * 2 * Tp * B * 3 * H * H
+    return {
+        'workload': 'configs[3] per-GPU shard: 8-patient MCCA-aligned input (d = 30), enc 2x bi-GRU H=512, dec 1x GRU, T=200 '
+                    "(T'=20), F=100, 2048 trials per GPU and step, dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW; 1 GPU, no collective",
+        'value': round(B / dt, 1), 'unit': 'trials/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warm,
+        'train_mflop_per_trial': round(fl / 1e6, 2), 'model_tflops': round(B / dt * fl / 1e12, 2),
+        'dtype': 'bf16x3' if XF.get_gemm_precision() == 'bf16x3' else 'f32',
+        'roofline': {'bound': 'hbm', 'kernel': 'gru_cluster_bwd_kernel (BPTT of one bidirectional H = 512 layer, 20 steps, ONE launch: '
+                                               'W_hh resident in a 16-workgroup cluster, gate gradients exchanged in-kernel)',
+                     'achieved': round(by_b / t_b / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by_b / t_b / 1e9 / HBM_PEAK_GBS, 4),
+                     'launch_us': round(t_b * 1e6, 1), 'bytes_per_launch': by_b, 'flops_per_launch': fl_rec, 'traffic': None,
+                     'also': {'kernel': 'gru_cluster_fwd_kernel (same layer, forward, gates saved)', 'bound': 'hbm',
+                              'achieved': round(by_f / t_f / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), 'launch_us': round(t_f * 1e6, 1),
+                              'bytes_per_launch': by_f, 'flops_per_launch': fl_rec}}}
+
+
+def fp32_record(c, dev, steps=20, warm=30):
+    """Third record: the headline workload with the matrix kernels in exact-fp32 MFMA mode (the reference's own arithmetic),
+    priced against the 157.3 TFLOP/s fp32 matrix peak."""
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    old = XF.get_gemm_precision()
+    XF.set_gemm_precision('fp32')
+    try:
+        _, step = _make_step(c, dev, 0)
+        dt = _timed_steps(step, steps, warm)
+    finally:
+        XF.set_gemm_precision(old)
+    fl = train_flops_per_trial(c)
+    tf = c['trials_per_gpu'] / dt * fl / 1e12
+    return {'dtype': 'f32', 'ms_per_step': round(dt * 1e3, 3), 'value': round(c['trials_per_gpu'] / dt, 1), 'unit': 'trials/s',
+            'model_tflops': round(tf, 2), 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+            'steps': steps, 'warmup': warm}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--headline-only', action='store_true', help='skip the configs[3] shard and fp32 sub-records')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default=None,
                     help='product precision of the matrix kernels (default: the library default, bf16x3)')
     ap.add_argument('--hidden', type=int, default=None, help='(exploration only) override the hidden size, e.g. 512 = cfg 4')
@@ -332,9 +431,16 @@ def main():
                                      'fp32 everywhere else' if precision == 'bf16x3' else 'fp32 MFMA')},
             'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
         }
+        out['config']['collective'] = (f'RCCL (torch.distributed backend {backend!r}) world {world}: SyncBN statistics + flat gradient '
+                                       f'all-reduce per step' if world > 1 else 'none (single process)')
+        out['rccl_world'] = world if (world > 1 and backend == 'nccl') else (0 if world == 1 else None)
         if not explore:
             # the capture runs one more training step: single process only (under DP it would issue collectives alone)
             out['roofline'] = time_dominant_kernel(model, c, capture_dominant_launch(step) if world == 1 else None)
+            if world == 1 and not args.headline_only:
+                out['north_star_shard'] = north_star_shard(dev)
+                if precision != 'fp32':
+                    out['fp32'] = fp32_record(c, dev)
         else:
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:

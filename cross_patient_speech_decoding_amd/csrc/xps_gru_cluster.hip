@@ -290,20 +290,21 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
     const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
 
-    // contraction wave w moves pieces [16 w, 16 w + 16) of a round (trials 8 w .. 8 w + 7 of the 32) in four groups of four
+    // gate wave 4 + h moves pieces [16 h, 16 h + 16) of a round (trials 8 h .. 8 h + 7 of the 32) in four groups of four
+    const int mvw = wave & 3;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
     auto dma_src = [&](int s_, int r_) -> const unsigned char* {
-        return xb + (size_t)(((s_ & 1) * p.ndir + dir) * p.Bp + m_base + 32 * r_) * (KP * 4) + (size_t)(wave * 16) * 1024 + lane * 16;
+        return xb + (size_t)(((s_ & 1) * p.ndir + dir) * p.Bp + m_base + 32 * r_) * (KP * 4) + (size_t)(mvw * 16) * 1024 + lane * 16;
     };
     auto dma_group = [&](const unsigned char* src, int buf, int grp) {      // grp = 0 .. 3 (compile time at every call site)
-        const int j = wave * 16 + grp * 4;                                  // first piece: a multiple of four = trial boundary
+        const int j = mvw * 16 + grp * 4;                                   // first piece: a multiple of four = trial boundary
         const unsigned base = lds0 + (unsigned)(buf * TILE) + (unsigned)((j >> 1) * TS);
         // pieces j .. j + 3 = (trial, half) (t, 0), (t, 1), (t + 1, 0), (t + 1, 1); the immediates add 0, 1024, 2048, 3072
         const unsigned h = BF ? PS : 1024;
         cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
     };
 
-    if (wave < 4) {
+    if (wave >= 4) {
         const unsigned char* src = dma_src(p.s_begin, 0);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) dma_group(src, it_begin & 1, g4);
@@ -334,35 +335,40 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             w.load(seg, rlive, kq, H - kbase, W);
         }
         CL_STAMP(sb2)
-        int s_nx = p.s_begin, r_nx = 1;                 // (step, round) of iteration it + 1
-        if (r_nx == NR) { r_nx = 0; ++s_nx; }
         for (int it = it_begin; it < it_end; ++it) {
             const unsigned char* tb = smem + (it & 1) * TILE;
-            const bool has_next = it + 1 < it_end;
-            const unsigned char* src = dma_src(s_nx, r_nx);
             f32x4 acc[2][3];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (BF) {
+            if constexpr (BF) {
+                // 16 steps (tile, chunk); the fragments of step i + 1 are requested before the MFMAs of step i
+                const unsigned char* rp0 = tb + n * TS + (kbase + 8 * kq) * 2;
+                bf16x8 bh[2], bl[2];
+                bh[0] = *reinterpret_cast<const bf16x8*>(rp0);
+                bl[0] = *reinterpret_cast<const bf16x8*>(rp0 + PS);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        if (has_next && (c & 3) == 0) dma_group(src, (it + 1) & 1, tt * 2 + (c >> 2));
-                        const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
-                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
-                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[g][c], bh, acc[tt][g], 0, 0, 0);
-                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bl, acc[tt][g], 0, 0, 0);
-                            acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], bh, acc[tt][g], 0, 0, 0);
-                        }
+                for (int i = 0; i < 16; ++i) {
+                    const int tt = i >> 3, c = i & 7;
+                    if (i + 1 < 16) {
+                        const unsigned char* rp = rp0 + ((i + 1) >> 3) * 16 * TS + ((i + 1) & 7) * 64;
+                        bh[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rp);
+                        bl[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rp + PS);
                     }
-                } else {
+                    const bf16x8 h8 = bh[i & 1], l8 = bl[i & 1];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[g][c], h8, acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], l8, acc[tt][g], 0, 0, 0);
+                        acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], h8, acc[tt][g], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
-                        if (has_next && (c & 7) == 0) dma_group(src, (it + 1) & 1, tt * 2 + (c >> 3));
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -384,9 +390,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
                     *reinterpret_cast<f32x4*>(xacc + ((wave * 2 + tt) * 3 + g) * 1024 + lane * 16) = acc[tt][g];
-            if (++r_nx == NR) { r_nx = 0; ++s_nx; }
             CL_STAMP(sb3)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
             CL_STAMP(sb0)
             __syncthreads();
             CL_STAMP(sb1)
@@ -400,6 +404,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     }
 
     // ---------------- gate waves ----------------
+    // They share their SIMD with a contraction wave that always has an MFMA ready; at equal priority the older contraction
+    // wave wins every arbitration and the gate math (a few hundred instructions per round) takes longer than the round's
+    // MFMAs.  With priority the gate wave's instructions go first whenever it has one, the MFMAs fill the rest.
+    __builtin_amdgcn_s_setprio(3);
     const int hw = wave - 4;
     const int hut = hw >> 1, te = hw & 1;              // unit tile, trial tile of the round
     const int j0 = cm.member * Cf::U + hut * 16;
@@ -424,11 +432,16 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         const int b = m_base + 32 * rn + 16 * te + n;
         const int bc = b < B ? b : B - 1;
         const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
+#ifdef XPS_CL_ABL_NOLOAD
+        in.gr = (f32x4){0.1f, 0.2f, 0.3f, 0.4f}; in.gz = in.gr; in.gn = in.gr; in.hp = (u32x4){0u, 0u, 0u, 0u};
+        (void)gp; (void)slot_prev;
+#else
         in.gr = *reinterpret_cast<const f32x4*>(gp);
         in.gz = *reinterpret_cast<const f32x4*>(gp + H);
         in.gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
         // own previous state (fp32), written by this lane one step ago (or by the init kernel)
         in.hp = __builtin_amdgcn_raw_buffer_load_b128(yr, (unsigned)((((long long)slot_prev * B + bc) * ldy + dir * H + juc) * 4), 0, AUX_SC1);
+#endif
     };
     // gates + hidden update of round (sn, rn) for this lane's trial and four units; exchange rows of the next step (every lane
     // stores: rows of pad trials / pad units carry zeros), then the outputs: h_t and (training) the saved gates, 1 or 5 stores,
@@ -492,18 +505,20 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         if (lane == 0) __hip_atomic_store(consumed + hw, (unsigned)rounds_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    // gate inputs live in two register slots (round parity relative to the launch's first round): requested during round
-    // it - 1, used during round it + 1.  The loop body is instantiated per slot so that no copy (which would wait for the
-    // loads) and no dynamic register index is needed.  (step, round) of rounds it - 1, it + 1, it + 2 are carried along.
-    EpiIn ein[2];
-    epi_load(p.s_begin, 0, ein[0]);
+    // gate inputs live in three register slots (round index mod 3 relative to the launch's first round): requested during
+    // round it - 2, used during round it + 1 (HBM latency under load exceeds one round).  The loop body is instantiated per
+    // slot so that no copy (which would wait for the loads) and no dynamic register index is needed.  (step, round) of
+    // rounds it - 1 and it + 2 are carried along.
+    EpiIn ein[3];
     int s_pv = p.s_begin, r_pv = -1;                    // round it - 1
-    int s_nx = p.s_begin, r_nx = 1;                     // round it + 1
-    if (r_nx == NR) { r_nx = 0; ++s_nx; }
-    int s_n2 = s_nx, r_n2 = r_nx + 1;                   // round it + 2
-    if (r_n2 == NR) { r_n2 = 0; ++s_n2; }
+    int s_n2 = p.s_begin, r_n2 = 0;                     // round it + 2 (starts as round it_begin, advanced below)
+    epi_load(s_n2, r_n2, ein[0]);
+    if (++r_n2 == NR) { r_n2 = 0; ++s_n2; }
+    if (it_begin + 1 < it_end) epi_load(s_n2, r_n2, ein[1]);
+    if (++r_n2 == NR) { r_n2 = 0; ++s_n2; }
     auto round_body = [&](int it, auto SLOT) {
-        constexpr int cur = decltype(SLOT)::value;            // slot of round it (and of round it + 2); round it - 1 / it + 1: the other
+        constexpr int cur = decltype(SLOT)::value;            // slot of round it; round it - 1: (cur + 2) % 3; round it + 2: the same slot
+        constexpr int prv = (cur + 2) % 3;
         // oldest group: flag of round it - 2 (its exchange rows were complete before the last barrier), flags of round it + 2
         if (p.handoff && wave == 4 && lane == 0 && it >= it_begin + 2) {
             int rp = r_pv - 1, sp = s_pv;
@@ -514,20 +529,30 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         unsigned fl = 0xffffffffu;
         if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r_n2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         CL_FENCE();
+        if (it + 1 < it_end) {                              // this wave's 16 pieces of round it + 1 (older than the exchange stores below)
+            int rn = r_pv + 2, sn = s_pv;
+            if (rn >= NR) { rn -= NR; ++sn; }
+            const unsigned char* src = dma_src(sn, rn);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) dma_group(src, (it + 1) & 1, g4);
+        }
+        CL_FENCE();
         int younger = 0;                                    // operations issued after the exchange stores (see cl_wait_vmcnt)
         if (it > it_begin) {
             take_products(it - it_begin);
-            epilogue(s_pv, r_pv, ein[cur ^ 1], prod);
+            epilogue(s_pv, r_pv, ein[prv], prod);
             younger += has_saved ? 5 : 1;
         }
         CL_FENCE();
-        if (it + 1 < it_end) {
-            epi_load(s_nx, r_nx, ein[cur ^ 1]);
+        if (it + 2 < it_end) {
+            epi_load(s_n2, r_n2, ein[prv]);                 // (the slot the gate math above has just released)
+#ifndef XPS_CL_ABL_NOLOAD
             younger += 4;
+#endif
         }
         CL_FENCE();
         CL_STAMP(sb3)
-        cl_wait_vmcnt(younger);                             // exchange rows complete; outputs / next inputs stay in flight
+        cl_wait_vmcnt(younger);                             // exchange rows complete; outputs / later inputs stay in flight
         if (do_poll) cl_wait(myflags + r_n2 * 16, (unsigned)s_n2, p.CS, lane, fl, p.status);
         CL_STAMP(sb0)
         __syncthreads();
@@ -537,18 +562,19 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         sb2 = sb1;
 #endif
         if (++r_pv == NR) { r_pv = 0; ++s_pv; }
-        if (++r_nx == NR) { r_nx = 0; ++s_nx; }
         if (++r_n2 == NR) { r_n2 = 0; ++s_n2; }
     };
-    for (int it = it_begin; it < it_end; it += 2) {
+    for (int it = it_begin; it < it_end; it += 3) {
         round_body(it, std::integral_constant<int, 0>{});
         if (it + 1 < it_end) round_body(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < it_end) round_body(it + 2, std::integral_constant<int, 2>{});
     }
     if (it_end > it_begin) {                                    // (outputs of the launch's last round; nobody waits for its flag)
         take_products(it_end - it_begin);
-        const bool odd = ((it_end - 1 - it_begin) & 1) != 0;
-        if (odd) epilogue(s_pv, r_pv, ein[1], prod);
-        else epilogue(s_pv, r_pv, ein[0], prod);
+        const int slot = (it_end - 1 - it_begin) % 3;
+        if (slot == 0) epilogue(s_pv, r_pv, ein[0], prod);
+        else if (slot == 1) epilogue(s_pv, r_pv, ein[1], prod);
+        else epilogue(s_pv, r_pv, ein[2], prod);
     }
     CL_STORE_STAMPS()
 }
@@ -860,6 +886,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     }
 
     // ---------------- gate waves ----------------
+    __builtin_amdgcn_s_setprio(3);   // (see the forward kernel)
     EpiIn ein;
     int pend_ps = -1, pend_r = 0;    // round whose contraction is complete and whose gate math is due
     auto finish = [&](int qlast) -> int {   // qlast: the g == 2 sub-iteration of the pending round; returns the group-C stores
@@ -945,12 +972,16 @@ ClPlan cl_plan(int B, int H, int ndir) {
     pl.CS = (H + pl.U - 1) / pl.U;
     const int max_blk = cus / (pl.CS * ndir);
     if (max_blk < 1) return pl;
-    int nblk = B / 128;                       // >= 4 rounds of 32 trials per cluster (the hand-off pipeline's depth)
+    // >= 6 rounds of 32 trials per cluster: the hand-off pipeline needs 4 (flags lag two rounds, polls lead two), and the gate
+    // waves request a round's inputs two rounds early: with 6 the previous step's h of the same trials (stored by the same lane)
+    // left the wave at least three rounds before it is requested again.  Small batches get empty (masked) rounds.
+    int nblk = B / 192;
     if (nblk > max_blk) nblk = max_blk;
-    if (nblk < 1) return pl;
+    if (nblk < 1) nblk = 1;
     pl.nblk = nblk;
     const int per = (B + nblk - 1) / nblk;
     pl.Mc = ((per + 31) / 32) * 32;
+    if (pl.Mc < 192) pl.Mc = 192;
     pl.NR = pl.Mc / 32;
     pl.Bp = pl.nblk * pl.Mc;
     pl.grid = ndir * pl.nblk * pl.CS;
@@ -959,7 +990,7 @@ ClPlan cl_plan(int B, int H, int ndir) {
     pl.xbuf_fwd = (size_t)2 * ndir * pl.Bp * pl.KP * 4;
     pl.xbuf_bwd = 3 * pl.xbuf_fwd;
     pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
-    pl.ok = pl.NR >= 4 && pl.xbuf_bwd < ((size_t)1 << 31);
+    pl.ok = pl.NR >= 6 && pl.xbuf_bwd < ((size_t)1 << 31);
     return pl;
 }
 

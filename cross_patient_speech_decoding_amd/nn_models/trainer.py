@@ -92,32 +92,32 @@ class FlatAdamW:
     def _reduce_tail_async(self):
         """Hook (autograd thread, during backward): all-reduce flat_g[split:] without blocking the main stream.
         Issued from an ordinary torch stream that first waits for the main stream and for the side stream carrying
-        the weight-gradient GEMMs; ``step()`` waits for the returned work handle."""
+        the weight-gradient GEMMs; ``step()`` waits for the returned work handle.
+
+        Every rank must issue the same collectives in the same order, so nothing here is allowed to change the
+        sequence on ONE rank: there is no local fallback.  A failure (of the stream set-up or of the collective call)
+        propagates out of ``loss.backward()`` and ends this rank; the other ranks end on the communicator's timeout /
+        abort instead of pairing a different collective with this one."""
         if self._early is not None:
             return
-        # only valid while every gradient of the tail lives in the flat buffer (direct accumulation)
+        # the tail is reduced in place: every gradient of it must still live in the flat buffer.  A rank-local
+        # deviation from that (someone replaced .grad) would desynchronise the collective sequence: fail hard.
         for p, view in zip(self.params, self._grad_views):
             if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                return
+                raise RuntimeError('FlatAdamW: a parameter gradient left the flat buffer while the overlapped gradient '
+                                   'all-reduce is enabled (use FlatAdamW.zero_grad(), not zero_grad(set_to_none=True)); '
+                                   'XPS_DP_OVERLAP=0 disables the overlap on EVERY rank')
         dev = self.flat_g.device
-        try:
-            idx = dev.index if dev.index is not None else torch.cuda.current_device()
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=idx)       # an ordinary torch stream for the collective
-            cs = self._comm_stream
-            cs.wait_stream(torch.cuda.current_stream(idx))              # gradients written on the main stream ...
-            side = XF._side_streams.get(idx)
-            if side is not None:
-                cs.wait_stream(side)                                    # ... and by the weight-gradient GEMMs on the side stream
-            with torch.cuda.stream(cs):
-                self._early = dist.all_reduce(self.flat_g[self._split:], op=self._op, group=self.group, async_op=True)
-        except Exception as e:                                          # never fatal: step() reduces everything instead
-            import warnings
-            warnings.warn(f'overlapped gradient all-reduce disabled ({type(e).__name__}: {e})')
-            self._early = None
-            self._split = None
-            self._avg, self._op = False, dist.ReduceOp.SUM              # most conservative collective from here on
-            XF.POST_SYNCBN_HOOKS[:] = [h for h in XF.POST_SYNCBN_HOOKS if getattr(h, '__self__', None) is not self]
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=idx)       # an ordinary torch stream for the collective
+        cs = self._comm_stream
+        cs.wait_stream(torch.cuda.current_stream(idx))              # gradients written on the main stream ...
+        side = XF._side_streams.get(idx)
+        if side is not None:
+            cs.wait_stream(side)                                    # ... and by the weight-gradient GEMMs on the side stream
+        with torch.cuda.stream(cs):
+            self._early = dist.all_reduce(self.flat_g[self._split:], op=self._op, group=self.group, async_op=True)
 
     @torch.no_grad()
     def step(self):

@@ -66,6 +66,17 @@ def sharded_alignment(group):
 
 
 def worker(rank, world, device, q):
+    if device == 'nccl':
+        # the production configuration: one process per GPU, RCCL (backend 'nccl'), device bound at init
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+        X, y = data()
+        res = hip_step(rank, world, X, y, dist.group.WORLD)
+        if rank == 0:
+            q.put(res)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dist.init_process_group('gloo', rank=rank, world_size=world)
     X, y = data()
     if device == 'align':
@@ -126,7 +137,7 @@ def main():
         X1, y1, k1 = sharded_alignment(None)
         assert ks == k1 and Xs.shape == X1.shape and (ys == y1).all()
         assert (Xs == X1).all(), float(abs(Xs - X1).max())          # deterministic decompositions: identical pooled set
-    if a.device == 'cuda':
+    if a.device in ('cuda', 'nccl'):
         X, y = data()
         g1, p1, n1, rv1 = [torch.as_tensor(v) if not isinstance(v, float) else v for v in hip_step(0, 1, X, y, None)]
         g2, p2, n2, rv2 = [torch.as_tensor(v) if not isinstance(v, float) else v for v in res]

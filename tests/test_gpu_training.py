@@ -128,6 +128,19 @@ def test_data_parallel_two_ranks_equal_single_process():
     assert 'DP_OK' in out.stdout
 
 
+def test_data_parallel_two_ranks_rccl_one_device_each():
+    """The production configuration: backend 'nccl' (= RCCL), one process per GPU, device bound at init_process_group,
+    ReduceOp.AVG, the tail of the flat gradient all-reduced asynchronously from the autograd thread.  Needs two GPUs: the
+    1-GPU boxes of this pool skip it, the driver's 8-GPU node (and any 2-GPU box) runs it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (one RCCL rank per device)')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', '2', '--device', 'nccl'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert 'DP_OK' in out.stdout
+
+
 def test_patient_sharded_alignment_equals_single_process():
     """SURVEY 8e, alignment: patients sharded over ranks (PCA + CCA on the owner's GPU, aligned trials broadcast):
     the pooled training set of 3 ranks is identical to the single-process one."""
