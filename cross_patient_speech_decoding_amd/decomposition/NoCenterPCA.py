@@ -30,23 +30,25 @@ class NoCenterPCA(BaseEstimator, TransformerMixin):
         return self
 
     def transform(self, X):
-        self._check_fit()
+        if not self._fit:
+            raise ValueError("PCA must be fit before transforming data.")      # message of the reference (NoCenterPCA.py:112-113)
         return LA.apply(LA.to_device(X), self._W_d).cpu().numpy()
 
     def fit_transform(self, X, y=None):
-        self.fit(X, y)
-        return self.transform(X)
+        return self.fit(X, y).transform(X)
 
     def _get_components(self, X, S):
-        if self.n_components is None or self.n_components >= min(X.shape):
+        """How many components to keep (semantics of the reference's NoCenterPCA.py:86-104): everything when n_components is
+        unset or not below min(X.shape) (with the same notice), the smallest count whose cumulative share of the squared
+        singular values reaches a fractional n_components, else n_components itself."""
+        limit = min(X.shape)
+        want = self.n_components
+        if want is None or want >= limit:
             print("n_components is None or greater than the number of features"
                   "/samples. Using n_components = min(X.shape)")
-            return min(X.shape)
-        elif self.n_components < 1:
-            cum_var = np.cumsum(S ** 2) / np.sum(S ** 2)
-            return int(np.argmax(cum_var >= self.n_components) + 1)
-        return int(self.n_components)
-
-    def _check_fit(self):
-        if not self._fit:
-            raise ValueError("PCA must be fit before transforming data.")
+            return limit
+        if want >= 1:
+            return int(want)
+        energy = np.square(np.asarray(S, dtype=np.float64))
+        share = np.cumsum(energy) / energy.sum()
+        return int(np.searchsorted(share, want, side='left')) + 1

@@ -176,6 +176,17 @@ class _FoldModule:
             np.savez(self.data_path / 'fold_data' / f'fold_{k}.npz',
                      **{n: _np(a) for n, a in arrays.items() if a is not None})
 
+    FOLD_KEYS = ('train_data', 'train_labels', 'val_data', 'val_labels', 'test_data', 'test_labels')
+
+    def load_folds(self):
+        """Re-populate the in-memory fold cache from ``fold_data/fold_{k}.npz`` (written by ``save_folds=True``): the
+        datasets carry the reference's names (datamodules.py:506-512); a missing validation split stays None."""
+        for k in range(self.folds):
+            path = self.data_path / 'fold_data' / f'fold_{k}.npz'
+            with np.load(path) as f:
+                self._folds[k] = {n: (torch.as_tensor(f[n]) if n in f.files else None) for n in self.FOLD_KEYS}
+        return self
+
     def _loader(self, which, shuffle):
         f = self._folds[self.current_fold]
         d, l = f[f'{which}_data'], f[f'{which}_labels']

@@ -138,10 +138,6 @@ class EncoderRNN(nn.Module):
 
     def forward_tm(self, x):
         """x: (T, B, In) time-major -> (y (T, B, 2H), last_hidden (1, B, H))."""
-        rnn = self.rnn
-        H, L = rnn.hidden_size, rnn.num_layers
-        T = x.shape[0]
-        y = x
         y, last = self.forward_tm_last(x)
         return y, last.unsqueeze(0)
 

@@ -17,7 +17,9 @@
  *     captured into a hipGraph;
  *   - return value: 0 = ok, negative = error (XPS_E_*); xps_last_error() returns a
  *     thread-local message.  No C++ exception crosses the boundary;
- *   - re-entrant; no global mutable state.
+ *   - re-entrant.  Global state: exactly two process-wide mode switches, both plain ints read at call time --
+ *     xps_set_gemm_precision (product precision of the matrix kernels) and xps_set_gru_cluster_mode (launch form of the
+ *     H > 256 recurrence) -- plus the immutable per-process cache of the device's CU count; nothing else outlives a call.
  *
  * Matrices are row-major float32 unless stated.  A "row map" (rpg, gs, ld) addresses
  * row i of a matrix at element offset  (i / rpg) * gs + (i % rpg) * ld ; an ordinary
@@ -53,7 +55,7 @@ int xps_abi_version(void);
 int xps_stream_create_low_priority(void** stream);
 int xps_stream_destroy(void* stream);
 /* Product precision of the tiled GEMM entry points below (xps_gemm_*) and of the fused GRU recurrence (xps_gru_seq_*,
- * H <= 128): 0 = fp32 MFMA, exact fp32 fma chains; 1 = bf16 split products (the default): every fp32 operand is split hi + lo in bf16 while it is staged and a product is
+ * every H): 0 = fp32 MFMA, exact fp32 fma chains; 1 = bf16 split products (the default): every fp32 operand is split hi + lo in bf16 while it is staged and a product is
  * accumulated in fp32 as lo*hi + hi*lo + hi*hi on the bf16 matrix pipe (relative product error ~2^-16; results
  * stay inside the 1e-4 parity bar; BASELINE.json names bf16 for this path).  Process-wide, initial value from
  * XPS_GEMM_PRECISION=fp32|bf16x3; returns XPS_E_INVALID for other modes. */
