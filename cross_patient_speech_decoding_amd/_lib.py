@@ -111,6 +111,11 @@ SIGNATURES = {
     'xps_apply_f64': (_i, [_vp, _i, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i, _i, _vp]),
     'xps_process_hg_f64_workspace': (_sz, [_i, _i, _i]),
     'xps_process_hg_f64': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xps_aug_time_shift_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'xps_aug_time_mask_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'xps_aug_scale_f32': (_i, [_vp, _vp, _i64, _f, _vp]),
+    'xps_aug_jitter_f32': (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
+    'xps_aug_time_warp_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'xps_dgemm_small': (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp]),
 }
 

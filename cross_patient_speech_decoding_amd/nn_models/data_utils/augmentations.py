@@ -1,40 +1,78 @@
-"""Whole-batch augmentations — same names, arguments and random-draw sources (numpy global RNG /
-torch global RNG, one draw per call) as the reference's nn_models/data_utils/augmentations.py
-(:13,32,51,65,79).  They run once per fold in DataModule.setup(), as in the reference."""
+"""Whole-batch augmentations — same names, arguments and random-draw sources (numpy global RNG / torch global RNG, one draw
+per call, in the same order) as the reference's nn_models/data_utils/augmentations.py (:13,32,51,65,79), computed by the HIP
+kernels of csrc/xps_augment.hip.  A tensor that already lives on the GPU stays there (augmentation per epoch on the device);
+a host tensor (what DataModule.setup() holds, as in the reference) is uploaded, augmented and returned on the host.  There is
+no CPU fallback: without the GPU these raise."""
 import numpy as np
 import torch
 
+from ..._lib import call
+from ..functional import _need_gpu, _ptr, _stream
+
+
+def _on_device(data):
+    if not torch.is_tensor(data):
+        data = torch.as_tensor(data)
+    if data.dim() != 3:
+        raise ValueError('augmentations expect (n_trials, n_timepoints, n_features) tensors')
+    host = not data.is_cuda
+    if host and not torch.cuda.is_available():
+        raise RuntimeError('cross_patient_speech_decoding_amd: the augmentation kernels need the MI355X (no CPU fallback)')
+    x = data.to('cuda', dtype=torch.float32).contiguous()
+    _need_gpu(x)
+    return x, host, data.dtype
+
+
+def _back(out, host, dtype):
+    out = out if dtype == torch.float32 else out.to(dtype)
+    return out.cpu() if host else out
+
 
 def time_warping(data, factor_range=(0.8, 1.2)):
-    """Linear temporal warp by a random factor, then linear resize back to the original length
-    (the reference uses scipy.ndimage.zoom(order=1) + torchvision Resize; torchvision is not in the
-    image, so both resamplings are torch linear interpolations along time)."""
+    """Linear warp of the time axis by a random factor (scipy.ndimage.zoom, order 1), then torchvision's Resize back to the
+    original length (bilinear, antialias), in one kernel."""
     factor = np.random.uniform(*factor_range)
-    x = data.permute(0, 2, 1)                                           # (N, C, T)
-    T = x.shape[-1]
-    warped = torch.nn.functional.interpolate(x, size=max(2, int(round(T * factor))), mode='linear',
-                                             align_corners=True)
-    back = torch.nn.functional.interpolate(warped, size=T, mode='linear', align_corners=False)
-    return back.permute(0, 2, 1).contiguous()
+    x, host, dt = _on_device(data)
+    N, T, C = x.shape
+    T2 = int(round(T * factor))                       # scipy.ndimage.zoom's output length
+    out = torch.empty_like(x)
+    call('xps_aug_time_warp_f32', _ptr(x), _ptr(out), N, T, C, max(T2, 1), _stream())
+    return _back(out, host, dt)
 
 
 def time_masking(data, mask_ratio=0.1):
     n_time = data.size(1)
     mask_size = int(n_time * mask_ratio)
     mask_start = np.random.randint(0, n_time - mask_size)
-    out = data.clone()
-    out[:, mask_start:mask_start + mask_size, :] = 0
-    return out
+    x, host, dt = _on_device(data)
+    N, T, C = x.shape
+    out = torch.empty_like(x)
+    call('xps_aug_time_mask_f32', _ptr(x), _ptr(out), N, T, C, int(mask_start), int(mask_size), _stream())
+    return _back(out, host, dt)
 
 
 def time_shifting(data, shift_max=20):
     shift = np.random.randint(-shift_max, shift_max)
-    return torch.roll(data, shifts=shift, dims=1)
+    x, host, dt = _on_device(data)
+    N, T, C = x.shape
+    out = torch.empty_like(x)
+    call('xps_aug_time_shift_f32', _ptr(x), _ptr(out), N, T, C, int(shift), _stream())
+    return _back(out, host, dt)
 
 
 def noise_jitter(data, noise_level=0.01):
-    return data + torch.randn_like(data) * noise_level
+    # the N(0, 1) draw comes from the generator of the device the data lives on, like the reference's torch.randn_like
+    noise = torch.randn_like(data if torch.is_tensor(data) else torch.as_tensor(data))
+    x, host, dt = _on_device(data)
+    nz = noise.to('cuda', dtype=torch.float32).contiguous()
+    out = torch.empty_like(x)
+    call('xps_aug_jitter_f32', _ptr(x), _ptr(nz), _ptr(out), x.numel(), float(noise_level), _stream())
+    return _back(out, host, dt)
 
 
 def scaling(data, scale_range=(0.9, 1.1)):
-    return data * np.random.uniform(*scale_range)
+    scale = np.random.uniform(*scale_range)
+    x, host, dt = _on_device(data)
+    out = torch.empty_like(x)
+    call('xps_aug_scale_f32', _ptr(x), _ptr(out), x.numel(), float(np.float32(scale)), _stream())
+    return _back(out, host, dt)

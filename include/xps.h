@@ -347,6 +347,24 @@ int xps_apply_f64(const void* X, int x_is_f32, int64_t ldx, const double* mean, 
 int xps_dgemm_small(const double* A, int64_t lda, int ta, const double* B, int64_t ldb, int tb,
                     double* C, int64_t ldc, int M, int N, int K, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Training-set augmentations on (trial x time x channel) fp32 tensors           */
+/* (nn_models/data_utils/augmentations.py:13-90).  The caller makes the random    */
+/* draw exactly as the reference does (numpy / torch global generators) and       */
+/* passes it in; x and out are [N][T][C], out != x for shift / warp.               */
+/*   time_shift : out = torch.roll(x, shift, dims=1)                 (:51-62)      */
+/*   time_mask  : out = x with [start, start + size) along time zeroed (:32-48)     */
+/*   scale      : out = x * scale                                      (:79-89)    */
+/*   jitter     : out = x + noise * level  (noise: the N(0,1) draw)    (:65-76)    */
+/*   time_warp  : scipy.ndimage.zoom(order=1) to T2 samples, then torchvision       */
+/*                Resize back to T (bilinear, antialias), fused          (:13-29)   */
+/* ------------------------------------------------------------------------- */
+int xps_aug_time_shift_f32(const float* x, float* out, int N, int T, int C, int shift, void* stream);
+int xps_aug_time_mask_f32(const float* x, float* out, int N, int T, int C, int start, int size, void* stream);
+int xps_aug_scale_f32(const float* x, float* out, int64_t n, float scale, void* stream);
+int xps_aug_jitter_f32(const float* x, const float* noise, float* out, int64_t n, float level, void* stream);
+int xps_aug_time_warp_f32(const float* x, float* out, int N, int T, int C, int T2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
