@@ -106,22 +106,26 @@ def _latent_dynamics_device(X_a, X_b, y_a, y_b, type='class'):
 
 
 def _cca_device(La, Lb):
-    """La (n, d_a), Lb (n, d_b) device matrices (rows = samples) -> numpy M_a, M_b, S."""
+    """La (n, d_a), Lb (n, d_b) device matrices (rows = samples) -> numpy M_a, M_b, S.
+
+    Reference (AlignCCA.py:259-283): centre, d = min(matrix_rank), thin QR of both, SVD of Q_a^T Q_b, M = pinv(R) [U | V][:, :d].
+    Here the orthonormal bases come from one-sided Jacobi SVDs of the centred data themselves (L = U S V^T, computed on the
+    tall matrix, not on its Gram matrix): the numerical rank follows LAPACK's rule on the singular values
+    (s > s_max * max(shape) * eps), the condition number is not squared, and with Q = U[:, :r] the canonical variates
+    L M = Q [U_k | V_k] are the reference's (any orthonormal basis of the same column space gives the same variates and the
+    same M for full-rank data)."""
     n = La.shape[0]
-    m_a, m_b = LA.col_mean(La), LA.col_mean(Lb)
-    C_aa = LA.xcov(La, None, m_a)
-    C_bb = LA.xcov(Lb, None, m_b)
-    C_ab = LA.xcov(La, Lb, m_a, m_b)
-    w_a, V_a = LA.eigh_psd(C_aa)
-    w_b, V_b = LA.eigh_psd(C_bb)
-    r_a, r_b = LA.rank_from_gram_eigs(w_a, n), LA.rank_from_gram_eigs(w_b, n)
+    Wa, s_a, V_a = LA.svd_tall_device(La, LA.col_mean(La))
+    Wb, s_b, V_b = LA.svd_tall_device(Lb, LA.col_mean(Lb))
+    r_a = LA.rank_from_singular_values(s_a, (n, La.shape[1]))
+    r_b = LA.rank_from_singular_values(s_b, (n, Lb.shape[1]))
     d = min(r_a, r_b)
-    W_a = LA.to_device(V_a[:, :r_a] / np.sqrt(w_a[:r_a]))
-    W_b = LA.to_device(V_b[:, :r_b] / np.sqrt(w_b[:r_b]))
-    K = LA.dgemm(LA.dgemm(W_a, C_ab, ta=True), W_b)
-    U, S, Vt = LA.svd(K)
-    M_a = LA.dgemm(W_a, LA.to_device(np.ascontiguousarray(U[:, :d]))).cpu().numpy()
-    M_b = LA.dgemm(W_b, LA.to_device(np.ascontiguousarray(Vt.T[:, :d]))).cpu().numpy()
+    # K = Q_a^T Q_b with Q = W^T diag(1 / s) restricted to the numerical range
+    G = LA.dgemm(Wa[:r_a].contiguous(), Wb[:r_b].contiguous(), tb=True).cpu().numpy()
+    K = G / s_a[:r_a, None] / s_b[None, :r_b]
+    U, S, Vt = LA.svd(LA.to_device(np.ascontiguousarray(K)))
+    M_a = (V_a[:, :r_a] / s_a[:r_a]) @ U[:, :d]
+    M_b = (V_b[:, :r_b] / s_b[:r_b]) @ Vt.T[:, :d]
     S = S[:d].copy()
     S[S < 0] = 0
     S[S >= 1] = 1

@@ -268,6 +268,31 @@ def eigh_sym_top(C, k):
     return (w - 2.0 * mu)[:k], V[:, :k]
 
 
+def svd_tall_device(A, mean=None):
+    """Thin SVD of a tall (n x d, n >= d) device matrix by one-sided Jacobi ON THE MATRIX ITSELF (no Gram matrix: singular
+    values keep their relative accuracy, so the numerical rank can follow LAPACK's rule and ill-conditioned data do not lose
+    half their digits).  ``mean``: column means subtracted first (apply kernel).  Returns (Wt, s, V): Wt (d x n) device
+    tensor whose row j is u_j * s_j, s (numpy, descending) and V (numpy, columns = right singular vectors), rows / columns
+    in the same (descending) order."""
+    A = A if A.dim() == 2 else A.reshape(-1, A.shape[-1])
+    n, d = A.shape
+    eye = torch.eye(d, dtype=F64, device=A.device)
+    Ac = apply(A, eye, mean)                          # centred float64 copy: (A - mean) I on the apply kernel
+    Wt = Ac.t().contiguous()                          # row j = column j
+    Vc = _jacobi(Wt, d, n)
+    s = torch.linalg.vector_norm(Wt, dim=1).cpu().numpy()
+    order = np.argsort(-s, kind='stable')
+    idx = torch.as_tensor(order, device=A.device)
+    return Wt[idx].contiguous(), s[order], Vc.cpu().numpy()[order].T
+
+
+def rank_from_singular_values(s, shape):
+    """numpy.linalg.matrix_rank semantics (the reference's AlignCCA.py:263-264): s > s_max * max(shape) * eps."""
+    if len(s) == 0 or s[0] <= 0:
+        return 0
+    return int((s > s[0] * max(shape) * EPS).sum())
+
+
 def rank_from_gram_eigs(w, n_rows):
     """Numerical rank of an (n_rows x d) matrix from the eigenvalues of its Gram matrix.
 

@@ -179,6 +179,10 @@ struct TnGroup {
     int n;
     int total_blocks;
     long long total_out;      // reduce outputs: sum of tiles * TN_TILE (padded tiles) + M column sums
+    // uniform != 0: every problem has the same K and the same k-split count; blocks are then ordered (k-split, problem, tile)
+    // with tile_start[p] = tiles of the problems before p and tiles_all = tiles of all problems
+    int uniform, tiles_all;
+    int tile_start[TN_MAXP];
 };
 
 constexpr int TN_TILE = BM * BN;       // floats of one output tile in a slab
@@ -211,14 +215,27 @@ __device__ inline void slab_decode(int e, int& row, int& col) {
 template <bool EDGE, bool BF = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
-    // logical order (problem, k-split, tile): the tiles of one k-chunk are neighbours on one XCD
+    // Logical order, uniform groups (the weight gradients of a GRU layer: same K = T' x B rows for every problem):
+    // (k-split, problem, tile) -- ALL blocks that read rows [kbeg, kend) of the operands are neighbours on one XCD and run at
+    // the same time, so a panel shared by several tiles AND several problems (dgi feeds dW_ih and dW_hh, x feeds both
+    // directions, h_prev the r/z and the n rows) comes from HBM once and from that XCD's L2 afterwards.
+    // Otherwise (problem, k-split, tile): only the tiles of one problem's k-chunk are neighbours.
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    int pi = 0;
+    int pi = 0, local;
+    if (g.uniform) {
+        const int zz = lid / g.tiles_all, rem = lid - zz * g.tiles_all;
 #pragma unroll 1
-    for (int i = 1; i < g.n; ++i)
-        if (lid >= g.p[i].block_start) pi = i;
+        for (int i = 1; i < g.n; ++i)
+            if (rem >= g.tile_start[i]) pi = i;
+        const int nt = ((g.p[pi].M + BM - 1) / BM) * g.p[pi].tiles_n;
+        local = zz * nt + (rem - g.tile_start[pi]);
+    } else {
+#pragma unroll 1
+        for (int i = 1; i < g.n; ++i)
+            if (lid >= g.p[i].block_start) pi = i;
+        local = lid - g.p[pi].block_start;
+    }
     const TnProb& P = g.p[pi];
-    const int local = lid - P.block_start;
     const int tiles_m = (P.M + BM - 1) / BM;
     const int ntiles = tiles_m * P.tiles_n;
     const int tile = local % ntiles, z = local / ntiles;
@@ -595,6 +612,40 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
     g.total_blocks = blocks;
     g.total_out = out;
     ws_floats = (size_t)off;
+    // same K everywhere: one common split count (the block budget over all tiles), blocks ordered by k-chunk first
+    g.uniform = 0;
+    g.tiles_all = 0;
+    bool same_k = n > 1;
+    for (int i = 1; i < n; ++i) same_k = same_k && probs[i].K == probs[0].K;
+    // opt-in (XPS_TN_UNIFORM=1): measured twice (rounds 1 and 2, cfg-2 layer-1 group) -- same launch time (151 vs 152 us) and
+    // the same fabric traffic within 1 %: co-resident blocks drift apart by more k-tiles than an XCD's L2 holds
+    static const bool allow = [] { const char* e = getenv("XPS_TN_UNIFORM"); return e && e[0] == '1'; }();
+    if (same_k && allow && probs[0].K > 0) {
+        int sp = (int)((target_blocks + tiles_total - 1) / tiles_total);
+        const int maxs = cdiv(probs[0].K, 64);
+        if (sp > maxs) sp = maxs;
+        if (sp < 1) sp = 1;
+        if (sp > 256) sp = 256;
+        const int kchunk = ((cdiv(probs[0].K, sp) + BKT - 1) / BKT) * BKT;
+        blocks = 0; off = 0;
+        int tstart = 0;
+        for (int i = 0; i < n; ++i) {
+            TnProb& P = g.p[i];
+            const int tiles = cdiv(P.M, BM) * cdiv(P.N, BN);
+            P.splits = sp; P.kchunk = kchunk;
+            P.slab_off = off;
+            P.block_start = blocks;          // (unused in uniform order)
+            g.tile_start[i] = tstart;
+            tstart += tiles;
+            blocks += tiles * sp;
+            off += (long long)sp * tn_split_stride(tiles, P.M, P.colsum != nullptr);
+        }
+        for (int i = n; i < TN_MAXP; ++i) g.tile_start[i] = 1 << 30;
+        g.tiles_all = tstart;
+        g.total_blocks = blocks;
+        ws_floats = (size_t)off;
+        g.uniform = 1;
+    }
     return 0;
 }
 }  // namespace

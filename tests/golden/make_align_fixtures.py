@@ -97,6 +97,39 @@ def fx_cca():
     Lb[3] = 0.5 * La[1] + 0.1 * rng.standard_normal(90)
     Ma, Mb, S = CCA_align(La.copy(), Lb.copy())
     out.update(raw_La=La, raw_Lb=Lb, raw_Ma=Ma, raw_Mb=Mb, raw_S=S)
+    # ---- round 2 (appended: the draws above are unchanged) --------------------------------------------------------------
+    # ill-conditioned but FULL-RANK views (channel scales 10^0 .. 10^-7 / 10^-9): LAPACK's rank rule on singular values
+    # (AlignCCA.py:263-264) keeps every channel; a Gram-eigenvalue rule would not.  The reference's answer is well defined here
+    # (uncertainty ~ eps * cond).
+    for name, span in (('illc7', 7.0), ('illc9', 9.0)):
+        Xa, ya = make_view(rng, Z, seqs, 48, 8)
+        Xb, yb = make_view(rng, Z, seqs, 40, 7, drop=4)
+        Xa = Xa * 10.0 ** (-span * np.arange(8) / 7.0)
+        Xb = Xb * 10.0 ** (-span * np.arange(7) / 6.0)
+        out.update({f'{name}_Xa': Xa, f'{name}_ya': ya, f'{name}_Xb': Xb, f'{name}_yb': yb})
+        for space in ('b_to_a', 'a_to_b'):
+            al = AlignCCA(return_space=space)
+            al.fit(Xa, Xb, ya, yb)
+            out[f'{name}_{space}_t'] = al.transform(Xb if space == 'b_to_a' else Xa)
+        out.update({f'{name}_M_a': al.M_a, f'{name}_M_b': al.M_b, f'{name}_S': al.canon_corrs})
+    # The rank-deficient case is NOT a function of its input in the reference: Householder QR completes Q with a direction made of
+    # rounding noise.  Evidence kept with the fixture: the reference re-run on the 'rdef' input perturbed by RELATIVE noise of
+    # 1e-16 (below one ulp of most entries) -- its own canonical correlations / transforms move by the amounts stored here.
+    Xa, ya, Xb, yb = out['rdef_Xa'], out['rdef_ya'], out['rdef_Xb'], out['rdef_yb']
+    prng = np.random.default_rng(99)
+    dS, dT = [], []
+    for _ in range(8):
+        Xa2 = Xa * (1.0 + 1e-16 * prng.standard_normal(Xa.shape))
+        Xb2 = Xb * (1.0 + 1e-16 * prng.standard_normal(Xb.shape))
+        al = AlignCCA(return_space='b_to_a')
+        al.fit(Xa2, Xb2, ya, yb)
+        if al.canon_corrs.shape != out['rdef_S'].shape:
+            continue
+        dS.append(np.abs(al.canon_corrs - out['rdef_S']).max())
+        t = al.transform(Xb)
+        dT.append(np.abs(t - out['rdef_b_to_a_t']).max() / np.abs(out['rdef_b_to_a_t']).max())
+    out['rdef_ref_selfdiff_S'] = np.array(dS)
+    out['rdef_ref_selfdiff_T'] = np.array(dT)
     np.savez_compressed(os.path.join(HERE, 'align_cca.npz'), **out)
 
 

@@ -112,7 +112,12 @@ def _check_rank_deficient(al, g, Xa, ya, Xb, yb):
     (shapes), and the values up to that chance-correlation term; what the HIP result must satisfy
     exactly: the CCA optimality conditions."""
     assert al.M_a.shape == g['rdef_M_a'].shape and al.M_b.shape == g['rdef_M_b'].shape == (7, 6)
-    assert np.abs(al.canon_corrs - g['rdef_S']).max() <= 0.05           # n = 170 samples -> ~0.08 chance level
+    # How far may the values be from the golden?  Not further than the reference is from ITSELF: the fixture holds the
+    # reference's own outputs for this input perturbed by relative noise of 1e-16 (below one ulp): its canonical
+    # correlations move by 0.03 .. 0.10 and its transforms by 18 .. 77 % (rdef_ref_selfdiff_*).  That spread -- not a
+    # tolerance picked to pass -- is the bound.
+    assert g['rdef_ref_selfdiff_S'].min() > 1e-3 and g['rdef_ref_selfdiff_T'].min() > 1e-2     # the golden is ill-defined at this level
+    assert np.abs(al.canon_corrs - g['rdef_S']).max() <= g['rdef_ref_selfdiff_S'].max()
     La, Lb = ao.shared_class_dynamics(Xa, Xb, ya, yb)
     La, Lb = La - La.mean(0), Lb - Lb.mean(0)
     Pa, Pb = La @ al.M_a, Lb @ al.M_b
@@ -128,7 +133,31 @@ def _check_rank_deficient(al, g, Xa, ya, Xb, yb):
     out = al.transform(Xb)
     ref = g['rdef_b_to_a_t']
     assert out.shape == ref.shape
-    assert np.abs(out - ref).max() / np.abs(ref).max() <= 0.1
+    assert np.abs(out - ref).max() / np.abs(ref).max() <= g['rdef_ref_selfdiff_T'].max()
+
+
+@pytest.mark.parametrize('case,tol_s,tol_t', [('illc7', 1e-8, 1e-6), ('illc9', 1e-7, 1e-5)])
+def test_align_cca_ill_conditioned_full_rank_vs_reference_golden(golden_dir, case, tol_s, tol_t):
+    """Views with condition numbers 2e7 / 6e8 (channel scales spanning 7 / 9 decades), full rank by LAPACK's rule on the
+    singular values (reference AlignCCA.py:263-264: tolerance s_max * max(shape) * eps ~ 4e-14).  A Gram-side method sees
+    eigenvalue ratios of 1e-15 / 1e-18 there (below ITS tolerance: it would drop channels and return other shapes) and loses
+    half the digits; the device path takes the SVD of the centred data themselves, keeps every channel like the reference and
+    matches it at the bounds of the well-conditioned cases (illc7) / at eps * cond (illc9)."""
+    g = _load(golden_dir, 'align_cca.npz')
+    Xa, ya, Xb, yb = (g[f'{case}_{k}'] for k in ('Xa', 'ya', 'Xb', 'yb'))
+    al = A().AlignCCA(return_space='b_to_a')
+    al.fit(Xa, Xb, ya, yb)
+    assert al.M_a.shape == g[f'{case}_M_a'].shape == (8, 7) and al.M_b.shape == g[f'{case}_M_b'].shape == (7, 7)   # no channel dropped
+    np.testing.assert_allclose(al.canon_corrs, g[f'{case}_S'], rtol=0, atol=tol_s)
+    for space, X in (('b_to_a', Xb), ('a_to_b', Xa)):
+        al.return_space = space
+        al._maps = {}
+        out = al.transform(X)
+        ref = g[f'{case}_{space}_t']
+        # per channel: the channels differ by up to nine decades in scale
+        scale = np.abs(ref).reshape(-1, ref.shape[-1]).max(axis=0)
+        rel = (np.abs(out - ref).reshape(-1, ref.shape[-1]).max(axis=0) / scale).max()
+        assert rel <= tol_t, (space, rel)
 
 
 def test_cca_align_function_and_inplace_centering(golden_dir):
