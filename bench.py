@@ -244,7 +244,8 @@ def _make_step(c, dev, rank, dropout=0.3):
     X, y = make_data(rank, c)
     X, y = X.to(dev), y.to(dev)
     model.train()
-    one = torch.ones((), device=dev)
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    one = XF.unit_gradient(dev)
 
     def step():
         opt.zero_grad()
@@ -367,7 +368,7 @@ def main():
     torch.manual_seed(99)                        # the same teacher-forcing coins on every rank
     model.train()
 
-    one = torch.ones((), device=dev)
+    one = XF.unit_gradient(dev)
 
     def step():
         opt.zero_grad()

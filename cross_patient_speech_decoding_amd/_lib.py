@@ -74,6 +74,7 @@ SIGNATURES = {
     'xps_transpose_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xps_bn_finalize_f32': (_i, [_vp, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp]),
     'xps_bn_apply_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i64, _i, _i, _vp]),
+    'xps_bn_finalize_apply_f32': (_i, [_vp, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _f, _vp, _i64, _i, _i, _vp]),
     'xps_bn_apply_eval_f32': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     'xps_bn_bwd_workspace': (_sz, [_i64, _i]),
     'xps_bn_bwd_reduce_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
@@ -92,6 +93,8 @@ SIGNATURES = {
     'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'xps_cross_entropy_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     'xps_cross_entropy_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    'xps_cross_entropy_loss_grad_f32_workspace': (_sz, [_i64]),
+    'xps_cross_entropy_loss_grad_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _vp]),
     'xps_ctc_loss_f32_workspace': (_sz, [_i, _i, _i]),
     'xps_ctc_loss_f32': (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xps_sumsq_f32_workspace': (_sz, [_i64]),

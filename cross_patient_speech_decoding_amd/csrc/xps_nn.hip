@@ -115,6 +115,46 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
     }
 }
 
+// finalize + apply in ONE launch: every block derives mean / rstd of all F channels from the (all-reduced) sums into LDS
+// with the arithmetic of bn_finalize_kernel (bitwise the same values), block 0 also stores them for the backward pass and
+// updates the running statistics; then the grid-stride normalisation of bn_apply_kernel.
+__global__ void bn_finalize_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats, double count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* mean_out, float* rstd_out, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float momentum, float eps,
+                                         const float* __restrict__ mask, float scale, float* __restrict__ out,
+                                         long long total, int F, int relu) {
+    extern __shared__ float bn_lds[];              // [F] scale = rstd * gamma, [F] shift = beta - mean * rstd * gamma ... kept as mean, rstd
+    float* s_mean = bn_lds;
+    float* s_rstd = bn_lds + F;
+    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+        const double m = (double)stats[c] / count;
+        double var = (double)stats[F + c] / count - m * m;
+        if (var < 0) var = 0;
+        const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[c] = mf;
+        s_rstd[c] = rf;
+        if (blockIdx.x == 0) {
+            mean_out[c] = mf;
+            rstd_out[c] = rf;
+            if (running_mean) {
+                const double unbiased = count > 1 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % F);
+        float v = (y[i] - s_mean[c]) * s_rstd[c] * gamma[c] + beta[c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        if (mask) v = v * mask[i] * scale;
+        out[i] = v;
+    }
+}
+
 __global__ void bn_apply_eval_kernel(const float* __restrict__ y, const float* __restrict__ rm, const float* __restrict__ rv,
                                      float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* __restrict__ out, long long total, int F, int relu) {
@@ -520,6 +560,20 @@ extern "C" int xps_bn_apply_f32(const float* y, const float* mean, const float* 
     return XPS_OK;
 }
 
+extern "C" int xps_bn_finalize_apply_f32(const float* y, const float* stats, double count, const float* gamma, const float* beta,
+                                         float* mean, float* rstd, float* running_mean, float* running_var,
+                                         int64_t* num_batches_tracked, float momentum, float eps, const float* drop_mask,
+                                         float drop_scale, float* out, int64_t rows, int F, int relu, void* stream) {
+    XPS_CHECK_ARG(y && stats && gamma && beta && mean && rstd && out && rows >= 1 && F >= 1 && F <= 8192 && count > 0, "bad argument");
+    XPS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
+    const long long total = (long long)rows * F;
+    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(ew_grid(total)), dim3(256), 2 * F * sizeof(float), (hipStream_t)stream,
+                       y, stats, count, gamma, beta, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked,
+                       momentum, eps, drop_mask, drop_scale, out, total, F, relu);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
 extern "C" int xps_bn_apply_eval_f32(const float* y, const float* running_mean, const float* running_var, float eps,
                                      const float* gamma, const float* beta, float* out, int64_t rows, int F,
                                      int relu, void* stream) {
@@ -668,6 +722,76 @@ extern "C" int xps_cross_entropy_fwd_f32(const float* logits, const int64_t* tar
                        logits, (const long long*)target, row_loss, (long long)rows, n_classes);
     XPS_CHECK_LAUNCH();
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, (long long)rows, loss);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+// Loss AND unit gradient in ONE launch (the three-kernel form costs two more ~5 us launches plus their host time per
+// step): every block handles 256 rows -- row losses, d(mean loss)/d(logits) = (softmax - onehot) / rows -- and leaves its
+// partial loss sum (double); the block that takes the last ticket adds the partials IN INDEX ORDER (the result does not depend
+// on which block that is) and resets the ticket for the next call.  Partials are published with agent-scope fences around
+// the ticket (cdna_hip_programming.md, Guideline 16): release before the atomic, acquire after it in the last block.
+__global__ __launch_bounds__(256) void ce_loss_grad_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                           float* __restrict__ row_loss, float* __restrict__ loss,
+                                                           float* __restrict__ dlogits, double* part, unsigned* ticket,
+                                                           long long rows, int C) {
+    __shared__ double sh[256];
+    __shared__ unsigned last;
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    double l = 0.0;
+    if (r < rows) {
+        const float* p = logits + r * C;
+        float mx = p[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(p[c] - mx);
+        const long long tg = target[r];
+        const float rl = (logf(s) + mx) - p[tg];
+        row_loss[r] = rl;
+        l = (double)rl;
+        if (dlogits) {
+            const float g = 1.f / (float)rows, inv = 1.f / s;
+            for (int c = 0; c < C; ++c) dlogits[r * C + c] = g * (expf(p[c] - mx) * inv - (c == tg ? 1.f : 0.f));
+        }
+    }
+    sh[threadIdx.x] = l;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = sh[0];
+        __threadfence();                                          // release: the partial before the ticket
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();                                          // acquire: every block's partial
+        double a = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) a += __hip_atomic_load(part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        loss[0] = (float)(a / (double)rows);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call on this stream
+    }
+}
+
+extern "C" size_t xps_cross_entropy_loss_grad_f32_workspace(int64_t rows) {
+    return (size_t)(cdiv(rows > 0 ? rows : 1, 256) + 2) * sizeof(double);
+}
+
+extern "C" int xps_cross_entropy_loss_grad_f32(const float* logits, const int64_t* target, float* row_loss, float* loss,
+                                               float* dlogits, void* workspace, size_t workspace_bytes, int64_t rows,
+                                               int n_classes, void* stream) {
+    XPS_CHECK_ARG(logits && target && row_loss && loss && rows >= 1 && n_classes >= 1, "bad argument");
+    if (!workspace || workspace_bytes < xps_cross_entropy_loss_grad_f32_workspace(rows) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+        xps_set_error("xps_cross_entropy_loss_grad_f32: workspace too small or misaligned");
+        return XPS_E_WORKSPACE;
+    }
+    const int blocks = cdiv(rows, 256);
+    unsigned* ticket = (unsigned*)workspace;              // FIRST word: its place must not depend on the row count (calls of
+    double* part = (double*)workspace + 2;                // different sizes share one zero-initialised buffer)
+    hipLaunchKernelGGL(ce_loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)target,
+                       row_loss, loss, dlogits, part, ticket, (long long)rows, n_classes);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

@@ -570,10 +570,9 @@ class TemporalConvFn(torch.autograd.Function):
                 count = _global_rows(rows, group, x.device, global_trials, Tp)
             mean = torch.empty(F, dtype=_f32, device=x.device)
             rstd = torch.empty(F, dtype=_f32, device=x.device)
-            call('xps_bn_finalize_f32', _ptr(stats), count, _ptr(mean), _ptr(rstd), _ptr(running_mean),
-                 _ptr(running_var), _ptr(num_batches_tracked), momentum, eps, F, _stream())
-            call('xps_bn_apply_f32', _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(drop_mask),
-                 drop_scale, _ptr(out), rows, F, int(relu), _stream())
+            call('xps_bn_finalize_apply_f32', _ptr(y), _ptr(stats), count, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                 _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), momentum, eps, _ptr(drop_mask), drop_scale,
+                 _ptr(out), rows, F, int(relu), _stream())
             ctx.save_for_backward(x, w2, y, out, mean, rstd, gamma, drop_mask)
             ctx.cfg = (B, T, Cin, F, k, stride, Tp, relu, drop_scale, count, group)
             ctx.conv_w = conv_w
@@ -831,8 +830,36 @@ def dropout(x, p, training):
     return DropoutFn.apply(x, p)
 
 
+_unit_grads = {}
+
+
+def unit_gradient(device):
+    """A resident scalar 1.0 on `device`: pass it to ``loss.backward(...)`` (autograd would otherwise launch a fill per step).
+    CrossEntropyFn recognises it and returns the gradient it computed in the forward launch without another kernel."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _unit_grads.get(key)
+    if t is None:
+        t = _unit_grads[key] = torch.ones((), dtype=_f32, device=device)
+    return t
+
+
+_ce_ws = {}
+
+
+def _ce_workspace(rows, device):
+    """Zero-initialised partial-sum / ticket buffer of the fused cross-entropy launch, one per (device, stream): the kernel
+    leaves the ticket at zero, so the buffer is reused by every step."""
+    nbytes = lib().xps_cross_entropy_loss_grad_f32_workspace(rows)
+    key = (device.index, _stream())
+    t = _ce_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _ce_ws[key] = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+    return t, nbytes
+
+
 class CrossEntropyFn(torch.autograd.Function):
-    """mean CE over rows (nn.CrossEntropyLoss defaults), deterministic reduction."""
+    """mean CE over rows (nn.CrossEntropyLoss defaults), deterministic reduction; loss and gradient in ONE launch."""
 
     @staticmethod
     def forward(ctx, logits, target):
@@ -842,18 +869,22 @@ class CrossEntropyFn(torch.autograd.Function):
         rows, Cn = logits.shape
         row_loss = torch.empty(rows, dtype=_f32, device=logits.device)
         loss = torch.empty(1, dtype=_f32, device=logits.device)
-        call('xps_cross_entropy_fwd_f32', _ptr(logits), _ptr(target), _ptr(row_loss), _ptr(loss), rows, Cn, _stream())
-        ctx.save_for_backward(logits, target)
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty_like(logits) if need else None
+        ws, nbytes = _ce_workspace(rows, logits.device)
+        call('xps_cross_entropy_loss_grad_f32', _ptr(logits), _ptr(target), _ptr(row_loss), _ptr(loss), _ptr(dl), _ptr(ws),
+             ws.numel(), rows, Cn, _stream())
+        ctx.unit = dl
         return loss.view(())
 
     @staticmethod
     def backward(ctx, gout):
-        logits, target = ctx.saved_tensors
-        rows, Cn = logits.shape
-        g = gout.reshape(1).contiguous().to(_f32)
-        dl = torch.empty_like(logits)
-        call('xps_cross_entropy_bwd_f32', _ptr(logits), _ptr(target), _ptr(g), _ptr(dl), rows, Cn, _stream())
-        return dl, None
+        dl = ctx.unit
+        key = (gout.device.type, gout.device.index)
+        one = _unit_grads.get(key)
+        if one is not None and gout.data_ptr() == one.data_ptr():
+            return dl, None                              # d loss / d loss = the resident 1.0: nothing to scale
+        return dl * gout.to(_f32), None
 
 
 def cross_entropy(logits, target):

@@ -307,10 +307,8 @@ class Trainer:
                 loss = model.training_step(batch, bi)
                 if world > 1:                       # global mean over unequal shards
                     loss = loss * (x.shape[0] * world / n_global)
-                one = self.__dict__.get('_one')
-                if one is None or one.device != loss.device or one.dtype != loss.dtype:
-                    one = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
-                loss.backward(one)                  # resident root gradient: no fill launch per step
+                loss.backward(XF.unit_gradient(loss.device) if loss.dtype == torch.float32 else torch.ones_like(loss))
+                # (resident root gradient: no fill launch per step, and the fused cross-entropy returns its gradient unscaled)
                 self.optimizer.step()
                 n = x.shape[0]
                 for k, v in model._xps_logged.items():

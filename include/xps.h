@@ -178,6 +178,11 @@ int xps_bn_apply_f32(const float* y, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* drop_mask, float drop_scale,
                      float* out, int64_t rows, int F, int relu, void* stream);
 /* eval mode: running statistics */
+/* xps_bn_finalize_f32 + xps_bn_apply_f32 in one launch (same values bit for bit; F <= 8192) */
+int xps_bn_finalize_apply_f32(const float* y, const float* stats, double count, const float* gamma, const float* beta,
+                              float* mean, float* rstd, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float momentum, float eps, const float* drop_mask,
+                              float drop_scale, float* out, int64_t rows, int F, int relu, void* stream);
 int xps_bn_apply_eval_f32(const float* y, const float* running_mean, const float* running_var, float eps,
                           const float* gamma, const float* beta, float* out,
                           int64_t rows, int F, int relu, void* stream);
@@ -258,6 +263,13 @@ int xps_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float*
                               float* loss, int64_t rows, int n_classes, void* stream);
 int xps_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* gout,
                               float* dlogits, int64_t rows, int n_classes, void* stream);
+/* Loss and UNIT gradient d(mean loss)/d(logits) in one launch (dlogits may be NULL: loss only).  `workspace`
+ * (xps_cross_entropy_loss_grad_f32_workspace bytes, 8-byte aligned) holds a ticket word (its first word) and per-block partial sums; the ticket must
+ * be ZERO at the first call and is left zero by every call: one zero-initialised buffer per stream serves all calls.            */
+size_t xps_cross_entropy_loss_grad_f32_workspace(int64_t rows);
+int xps_cross_entropy_loss_grad_f32(const float* logits, const int64_t* target, float* row_loss, float* loss,
+                                    float* dlogits, void* workspace, size_t workspace_bytes, int64_t rows,
+                                    int n_classes, void* stream);
 /* CTC loss of the realtime CTC-RNN family (realtime_sim/realtime_nn_model.py:150, :213-224:
  * nn.CTCLoss(blank, reduction='mean', zero_infinity) on log_softmax(logits)).  logits [T][B][C] TIME-major raw
  * scores (the log-softmax is fused); targets [B][target_stride] int64 (padded); lengths int64 [B].
