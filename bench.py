@@ -297,6 +297,45 @@ def north_star_shard(dev, steps=10, warm=10):
                               'bytes_per_launch': by_f, 'flops_per_launch': fl_rec}}}
 
 
+def alignment_record(dev):
+    """Fourth record: latent alignment at the north-star shape (patients of 2048 trials x 200 samples x 128 channels, fp32,
+    resident in HBM like the training inputs): fits / s of the per-patient PCA(0.95), of the pairwise CCA fit on the PCA latents
+    (reference: AlignCCA inside process_aligner, datamodules.py:542-565) and of the 4-view MCCA fit (AlignMCCA.py:140-154);
+    HIP events on the launch stream, median of 5."""
+    import numpy as np
+    from cross_patient_speech_decoding_amd import alignment as A
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    P = 4
+    pats = [make_patient(p, 2048, T=200, C=128) for p in range(P)]
+    Xd = [torch.from_numpy(x).to(dev) for x, _ in pats]
+    ys = [y for _, y in pats]
+
+    def med(fn, n=5):
+        fn()
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[n // 2]
+    pca = A.PCA(0.95)
+    t_pca = med(lambda: pca.fit(Xd[0].reshape(-1, 128)))
+    Z = [A.PCA(0.95).fit(x.reshape(-1, 128)).transform(x.reshape(-1, 128)).reshape(2048, 200, -1) for x in Xd[:2]]
+    al = A.AlignCCA()
+    t_cca = med(lambda: al.fit(Z[0], Z[1], ys[0], ys[1]))
+    t_tr = med(lambda: al.transform(Z[1]))
+    m = A.AlignMCCA(n_components=30, regs=0.5)
+    t_mcca = med(lambda: m.fit(Xd, ys), n=3)
+    by = Xd[0].numel() * 4
+    return {'workload': 'north-star patients (2048 trials x 200 x 128 ch fp32 = 210 MB each), inputs resident in HBM',
+            'pca_fit': {'ms': round(t_pca * 1e3, 2), 'fits_per_s': round(1 / t_pca, 1), 'input_GB_per_s': round(by / t_pca / 1e9, 1)},
+            'cca_fit': {'ms': round(t_cca * 1e3, 2), 'fits_per_s': round(1 / t_cca, 1), 'latent_dims': [int(Z[0].shape[-1]), int(Z[1].shape[-1])]},
+            'cca_transform': {'ms': round(t_tr * 1e3, 2)},
+            'mcca_fit_4_views': {'ms': round(t_mcca * 1e3, 2), 'fits_per_s': round(1 / t_mcca, 2), 'D': 4 * 128}}
+
+
 def fp32_record(c, dev, steps=20, warm=30):
     """Third record: the headline workload with the matrix kernels in exact-fp32 MFMA mode (the reference's own arithmetic),
     priced against the 157.3 TFLOP/s fp32 matrix peak."""
@@ -442,6 +481,7 @@ def main():
                 out['north_star_shard'] = north_star_shard(dev)
                 if precision != 'fp32':
                     out['fp32'] = fp32_record(c, dev)
+                out['alignment'] = alignment_record(dev)
         else:
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:

@@ -85,8 +85,8 @@ class AlignCCA:
 
 
 def _apply_host(X, W_dev):
-    """X (..., d_in) ndarray or tensor -> float64 ndarray (..., d_out) = X @ W on the device."""
-    return LA.apply(LA.to_device(X), W_dev).cpu().numpy()
+    """X (..., d_in) ndarray or tensor -> float64 (..., d_out) = X @ W on the device (ndarray; a device tensor stays one)."""
+    return LA.like_input(LA.apply(LA.to_device(X), W_dev), X)
 
 
 def _latent_dynamics_device(X_a, X_b, y_a, y_b, type='class'):

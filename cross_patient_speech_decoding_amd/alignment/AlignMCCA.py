@@ -64,7 +64,7 @@ class DeviceMCCA:
         return self
 
     def transform_view(self, X, view):
-        return LA.apply(LA.to_device(X), self._load_d[view], self._means_d[view]).cpu().numpy()
+        return LA.like_input(LA.apply(LA.to_device(X), self._load_d[view], self._means_d[view]), X)
 
     def transform(self, Xs):
         return [self.transform_view(x, i) for i, x in enumerate(Xs)]

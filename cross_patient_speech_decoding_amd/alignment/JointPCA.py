@@ -58,7 +58,7 @@ class JointPCA:
         return (*[self._transform_single(x, i) for i, x in enumerate(X)],)
 
     def _transform_single(self, X, idx):
-        return LA.apply(LA.to_device(X), self._w(idx)).cpu().numpy()
+        return LA.like_input(LA.apply(LA.to_device(X), self._w(idx)), X)
 
     def _check_fit(self):
         try:

@@ -70,7 +70,7 @@ class PCA:
 
     def transform(self, X):
         self._check()
-        return self.transform_device(LA.to_device(X)).cpu().numpy()
+        return LA.like_input(self.transform_device(LA.to_device(X)), X)
 
     def fit_transform(self, X, y=None):
         return self.fit(X).transform(X)

@@ -346,3 +346,27 @@ def test_eigh_sym_top_indefinite_matrix():
         wr, Vr = np.linalg.eigh(C)
         np.testing.assert_allclose(w, wr[::-1][:k], atol=1e-10 * np.abs(wr).max())
         assert np.abs(C @ V - V * w).max() <= 1e-10 * np.abs(wr).max()
+
+
+def test_device_resident_inputs_stay_on_the_device(golden_dir):
+    """A device tensor in -> a device tensor out (no PCIe round trip between alignment stages), same values as the ndarray path."""
+    g = _load(golden_dir, 'align_cca.npz')
+    Xa, ya, Xb, yb = (g[f'full_{k}'] for k in ('Xa', 'ya', 'Xb', 'yb'))
+    al = A().AlignCCA()
+    al.fit(torch.from_numpy(Xa).cuda(), torch.from_numpy(Xb).cuda(), ya, yb)
+    out_d = al.transform(torch.from_numpy(Xb).cuda())
+    assert isinstance(out_d, torch.Tensor) and out_d.is_cuda and out_d.dtype == torch.float64
+    out_h = al.transform(Xb)
+    assert isinstance(out_h, np.ndarray)
+    np.testing.assert_array_equal(out_d.cpu().numpy(), out_h)
+    rel = np.abs(out_h - g['full_b_to_a_t']).max() / np.abs(g['full_b_to_a_t']).max()
+    assert rel <= 1e-6
+    pca = A().PCA(0.95)
+    Z = pca.fit(torch.from_numpy(Xa).cuda().reshape(-1, Xa.shape[-1])).transform(torch.from_numpy(Xa).cuda().reshape(-1, Xa.shape[-1]))
+    assert Z.is_cuda
+    np.testing.assert_array_equal(Z.cpu().numpy(), pca.transform(Xa.reshape(-1, Xa.shape[-1])))
+    m = A().AlignMCCA(n_components=3, regs=0.5)
+    m.fit([torch.from_numpy(Xa).cuda(), torch.from_numpy(Xb).cuda()], [ya, yb])
+    t = m.transform(torch.from_numpy(Xb).cuda(), idx=1)
+    assert t.is_cuda and tuple(t.shape) == Xb.shape[:2] + (3,)
+    np.testing.assert_array_equal(t.cpu().numpy(), m.transform(Xb, idx=1))
