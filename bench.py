@@ -281,6 +281,14 @@ def north_star_shard(dev, steps=10, warm=10):
     by_f = 4 * 2 * Tp * B * (3 * H + H + 4 * H)              # gi in, h + saved gates (r, z, n, q) out
     by_b = 4 * 2 * Tp * B * (4 * H + H + H + 3 * H + H)      # saved gates, dy, h_prev in; dgi, dghn out
     fl_rec = 2.0 * 2 * Tp * B * 3 * H * H
+    traffic = {}
+    try:                                   # HBM-side bytes per launch from the PMC passes kept under profiles/round2 (collected offline)
+        with open(os.path.join(ROOT, 'profiles', 'round2', 'pmc_traffic.json')) as f:
+            pj = json.load(f)
+        sfx = '_bf16x3' if XF.get_gemm_precision() == 'bf16x3' else ''
+        traffic = {'bwd': pj['gru_cluster_bwd_kernel' + sfx]['hbm_bytes_per_launch'], 'fwd': pj['gru_cluster_fwd_kernel' + sfx]['hbm_bytes_per_launch']}
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         'workload': 'configs[3] per-GPU shard: 8-patient MCCA-aligned input (d = 30), enc 2x bi-GRU H=512, dec 1x GRU, T=200 '
                     "(T'=20), F=100, 2048 trials per GPU and step, dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW; 1 GPU, no collective",
@@ -290,11 +298,11 @@ def north_star_shard(dev, steps=10, warm=10):
         'roofline': {'bound': 'hbm', 'kernel': 'gru_cluster_bwd_kernel (BPTT of one bidirectional H = 512 layer, 20 steps, ONE launch: '
                                                'W_hh resident in a 16-workgroup cluster, gate gradients exchanged in-kernel)',
                      'achieved': round(by_b / t_b / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by_b / t_b / 1e9 / HBM_PEAK_GBS, 4),
-                     'launch_us': round(t_b * 1e6, 1), 'bytes_per_launch': by_b, 'flops_per_launch': fl_rec, 'traffic': None,
+                     'launch_us': round(t_b * 1e6, 1), 'bytes_per_launch': by_b, 'flops_per_launch': fl_rec, 'traffic': traffic.get('bwd'),
                      'also': {'kernel': 'gru_cluster_fwd_kernel (same layer, forward, gates saved)', 'bound': 'hbm',
                               'achieved': round(by_f / t_f / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), 'launch_us': round(t_f * 1e6, 1),
-                              'bytes_per_launch': by_f, 'flops_per_launch': fl_rec}}}
+                              'bytes_per_launch': by_f, 'flops_per_launch': fl_rec, 'traffic': traffic.get('fwd')}}}
 
 
 def alignment_record(dev):
