@@ -1,29 +1,32 @@
-// Cluster-persistent GRU recurrence for 128 < H <= 512 on gfx950 (the north-star shape: H = 512 / 500,
+// Cluster-persistent GRU recurrence for 256 < H <= 512 on gfx950 (the north-star shape: H = 512 / 500,
 // nn_models/models.py:661-699).  W_hh (3H x H, 3 MB at H = 512) does not fit one CU, so a CLUSTER of
-// CS workgroups (one per CU) shares it: member m keeps the rows of its U hidden units of all three gates
-// resident in the VGPRs of its four waves for the WHOLE sequence (192 registers per lane: fp32, or the
-// bf16 hi/lo split made once per launch) and the cluster works on Mc trials.  Per step a member needs the
+// CS = 16 workgroups (one per CU) shares it: member m keeps the rows of its 32 hidden units of all three gates
+// resident in the VGPRs of its four CONTRACTION waves for the WHOLE sequence (192 registers per lane: fp32, or
+// the bf16 hi/lo split made once per launch) and the cluster works on Mc trials.  Per step a member needs the
 // complete previous state h_{t-1} of its trials (forward) or the complete gate gradients (backward): the
-// members exchange them through a small ping-pong buffer in global memory (L2), inside the launch.
+// members exchange them through a ping-pong buffer in global memory (L2), inside the launch.  DESIGN.md 4.1.
 //
-//   forward : H in (256, 512]: U = 32, CS = H/32 (16), wave (ut, kh) owns 16 units x 3 gates x 256 k
-//             H in (128, 256]: U = 64, CS = H/64 (4),  wave ut owns 16 units x 3 gates x 256 k
-//   grid    : ndir x nblk clusters, nblk = trial blocks per direction, <= one workgroup per CU
-//   round   : 32 trials (two 16-trial MFMA column tiles); per round a wave issues 144 MFMAs
-//             (v_mfma_f32_16x16x32_bf16 on split operands: lo*hi + hi*lo + hi*hi; fp32 mode: 16x16x4 f32),
-//             the two k-halves of a unit tile swap their partial sums through LDS and each runs the gate
-//             math of one trial tile.  Lane (n, kq) owns trial n and FOUR CONSECUTIVE units: every global
-//             access is a 16-byte vector.
+//   grid    : ndir x nblk clusters of 16 workgroups x 512 threads, <= one workgroup per CU
+//   round   : 32 trials (two 16-trial MFMA column tiles); the operand image of a round (32 x 512 states, split
+//             into bf16 hi / lo planes by the PRODUCER; fp32 mode: f32) is one contiguous 64 KiB, moved by
+//             LDS-DMA (global_load_lds_dwordx4 sc1, 1-KiB pieces) into a double-buffered, bank-conflict-free
+//             LDS image.
+//   waves   : 0-3 contract (wave (ut, kh): 16 units x 3 gates x 256 k; 144 MFMAs per round: v_mfma_f32_16x16x32_bf16
+//             on split operands lo*hi + hi*lo + hi*hi, fp32 mode 16x16x4 f32) and hand the products over through LDS;
+//             4-7 sum the k-halves, run the gate math of one (unit tile, trial tile) each, store outputs and exchange
+//             planes, prefetch the gate inputs two rounds ahead, publish flags (and, forward, issue the DMA pieces).
+//             Lane (n, kq) owns trial n and FOUR CONSECUTIVE units: every global access is a 16-byte vector.
 //
 // Hand-off protocol (MI355X_MICROARCH.md "Valid forms", first table row; cdna_hip_programming.md G16 R1):
-// every exchanged byte is stored write-through (sc1) and loaded with sc1 loads to registers; a member
-// publishes round r of step s by ONE lane's sc1 flag store after a workgroup barrier that every storing
-// wave reaches only once loads it issued AFTER those stores have returned (vmcnt retires in order, so the
-// stores have completed); consumers poll the CS flags of the round with one sc1 load by one wave, and the
-// other waves load behind a barrier that wave joins afterwards.  Publication lags one round and polls run
-// two rounds ahead, so in steady state nobody waits; the dependency chain needs NR >= 4 rounds per
-// cluster (checked on the host).  Every spin is bounded (status word, checked by the caller).
-// XPS_GRU_CLUSTER=steps runs the SAME kernels one step per launch (no in-kernel hand-off at all).
+// exchanged bytes are loaded with sc1 (L1 bypass) and stored write-through (sc1) -- or with plain write-back
+// stores when the cluster has verified at run time that all members sit on one XCD (one L2).  A member
+// publishes round r of step s by ONE lane's sc1 flag store after every storing wave has waited for its
+// exchange stores (counted s_waitcnt vmcnt: vmcnt retires in issue order and the issue order of a gate wave
+// is pinned by CL_FENCE) and the workgroup barrier; consumers poll the 16 flags of a round with one sc1 load
+// by one wave, the others load behind a barrier that wave joins afterwards.  Publication lags and polls lead
+// two rounds, so in steady state nobody waits; the dependency chain needs NR >= 6 rounds per cluster (cl_plan).
+// Every spin is bounded (status word, checked by the caller).  XPS_GRU_CLUSTER=steps runs the SAME kernels one
+// step per launch (no in-kernel hand-off at all) and must give the same bits.
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
