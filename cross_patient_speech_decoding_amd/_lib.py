@@ -53,6 +53,8 @@ SIGNATURES = {
     'xps_stream_destroy': (_i, [_vp]),
     'xps_set_gemm_precision': (_i, [_i]),
     'xps_get_gemm_precision': (_i, []),
+    'xps_set_gemm_big_tiles': (_i, [_i]),
+    'xps_get_gemm_big_tiles': (_i, []),
     'xps_gemm_nt_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),
     'xps_gemm_nn_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _i, _i, _i, _i, _vp]),
     'xps_gemm_nt_multi_f32': (_i, [_vp, _rm, _vp, _rm, _vp, _rm, _vp, _i, _i, _i, _i, _vp]),

@@ -21,6 +21,7 @@
 #include <atomic>
 #include "xps_common.h"
 #include "xps_gemm_tile.h"
+#include "xps_gemm_big.h"
 using namespace xps_tile;
 #ifndef XPS_GEMM_DEFAULT_MODE
 #define XPS_GEMM_DEFAULT_MODE 1
@@ -171,13 +172,14 @@ struct TnProb {
     int M, N, K, accumulate;
     int splits, kchunk, tiles_n, vecA, vecB;
     long long slab_off;       // float offset of this problem's slabs in the workspace
-    int block_start;          // first flat block id
-    int pad_;
+    int block_start;          // first flat block id (of the launch that serves this problem)
+    int big;                  // != 0: served by the 256 x 256 tile kernel (gemm_big_tn_kernel), same slab layout
 };
 struct TnGroup {
     TnProb p[TN_MAXP];
     int n;
-    int total_blocks;
+    int total_blocks;         // blocks of the 128 x 128 launch (problems with big == 0)
+    int total_blocks_big;     // blocks of the 256 x 256 launch (problems with big != 0)
     long long total_out;      // reduce outputs: sum of tiles * TN_TILE (padded tiles) + M column sums
     // uniform != 0: every problem has the same K and the same k-split count; blocks are then ordered (k-split, problem, tile)
     // with tile_start[p] = tiles of the problems before p and tiles_all = tiles of all problems
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
         local = zz * nt + (rem - g.tile_start[pi]);
     } else {
 #pragma unroll 1
-        for (int i = 1; i < g.n; ++i)
-            if (lid >= g.p[i].block_start) pi = i;
+        for (int i = 0; i < g.n; ++i)
+            if (!g.p[i].big && lid >= g.p[i].block_start) pi = i;
         local = lid - g.p[pi].block_start;
     }
     const TnProb& P = g.p[pi];
@@ -360,6 +362,103 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 tiles on 8 waves (xps_gemm_big.h): large interior shapes in bf16 split-product mode.
+// ---------------------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+
+// C (+)= A B (+ A2 B2) + bias, plain leading dimensions.  1-D grid, logical order (m-tile, n-tile).
+template <bool AK, bool BK>
+__global__ __launch_bounds__(512, 1) void gemm_big_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
+                                                           long long ldb, const float* __restrict__ A2, const float* __restrict__ B2,
+                                                           int K2, float* __restrict__ C, long long ldc,
+                                                           const float* __restrict__ bias, int N, int K, int accumulate) {
+    xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
+    const int tiles_n = N / xps_big::TN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * xps_big::TM, n0 = (lid % tiles_n) * xps_big::TN;
+    f32x16 acc[4][2];
+    xps_big::big_zero(acc);
+    f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
+    xps_big::BigLoader<AK> la;
+    xps_big::BigLoader<BK> lb;
+    la.init(A, lda, m0, 0, threadIdx.x);
+    lb.init(B, ldb, n0, 0, threadIdx.x);
+    xps_big::big_pipeline<AK, BK>(acc, nocs, false, la, lb, K / BKT, st);
+    if (A2) {
+        la.init(A2, lda, m0, 0, threadIdx.x);
+        lb.init(B2, ldb, n0, 0, threadIdx.x);
+        xps_big::big_pipeline<AK, BK>(acc, nocs, false, la, lb, K2 / BKT, st);
+    }
+    xps_big::big_store_c(acc, C, ldc, bias, m0, n0, accumulate);
+}
+
+// same A, up to 4 (B, bias, C): logical order (m-tile, problem, n-tile)
+__global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* __restrict__ A, long long lda, NtMulti pm, long long ldb,
+                                                                    long long ldc, int N, int K, int nprob) {
+    xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
+    const int tiles_n = N / xps_big::TN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_m = nprob * tiles_n, rem = lid % per_m;
+    const int z = rem / tiles_n;
+    const int m0 = (lid / per_m) * xps_big::TM, n0 = (rem % tiles_n) * xps_big::TN;
+    f32x16 acc[4][2];
+    xps_big::big_zero(acc);
+    f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
+    xps_big::BigLoader<true> la, lb;
+    la.init(A, lda, m0, 0, threadIdx.x);
+    lb.init(pm.B[z], ldb, n0, 0, threadIdx.x);
+    xps_big::big_pipeline<true, true>(acc, nocs, false, la, lb, K / BKT, st);
+    xps_big::big_store_c(acc, pm.C[z], ldc, pm.bias[z], m0, n0, 0);
+}
+
+// grouped weight gradients: the problems of a TnGroup marked `big`; block = (problem, k-split, 256 x 256 tile); slabs in
+// the layout of the 128 x 128 kernel (four sub-tiles per block) so that gemm_tn_grouped_reduce serves both launches
+__global__ __launch_bounds__(512, 1) void gemm_big_tn_kernel(TnGroup g, float* __restrict__ ws) {
+    xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int pi = -1;
+#pragma unroll 1
+    for (int i = 0; i < g.n; ++i)
+        if (g.p[i].big && lid >= g.p[i].block_start) pi = i;
+    const TnProb& P = g.p[pi];
+    const int local = lid - P.block_start;
+    const int tiles_n = P.N / xps_big::TN, ntiles = (P.M / xps_big::TM) * tiles_n;
+    const int tile = local % ntiles, z = local / ntiles;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int kbeg = z * P.kchunk, kend = min(P.K, kbeg + P.kchunk);
+    const long long ntiles128 = (long long)(P.M / BM) * P.tiles_n;
+    const long long split_stride = tn_split_stride(ntiles128, P.M, P.colsum != nullptr);
+    float* slab = ws + P.slab_off + (long long)z * split_stride;
+    const bool want_cs = P.colsum && tn == 0;
+    f32x16 acc[4][2];
+    xps_big::big_zero(acc);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    xps_big::BigLoader<false> la, lb;
+    la.init(P.A, P.ra.ld, tm * xps_big::TM, kbeg, threadIdx.x);
+    lb.init(P.B, P.rb.ld, tn * xps_big::TN, kbeg, threadIdx.x);
+    xps_big::big_pipeline<false, false>(acc, csum, want_cs, la, lb, (kend - kbeg) / BKT, st);
+    float* sub[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        sub[s] = slab + ((long long)(2 * tm + (s >> 1)) * P.tiles_n + 2 * tn + (s & 1)) * TN_TILE;
+    xps_big::big_slab_store(acc, sub);
+    if (want_cs) {
+        // thread (k rows tid / 64 + {0, 8}, x group tid % 64) holds the sums of columns 4 xg .. 4 xg + 3 over its k rows:
+        // the eight waves are folded through LDS in a fixed order (big_pipeline ends with a barrier: the stage is free)
+        float* red = reinterpret_cast<float*>(big_smem);
+        const int tid = threadIdx.x;
+        *reinterpret_cast<f32x4*>(&red[(tid >> 6) * 256 + (tid & 63) * 4]) = csum;
+        __syncthreads();
+        if (tid < 256) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w * 256 + tid];
+            slab[ntiles128 * TN_TILE + tm * xps_big::TM + tid] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long slab_stride,
                                                             float* __restrict__ C, RowMap rc, int M, int N, int accumulate) {
     __shared__ float part[4][RED_OUT];
@@ -418,6 +517,25 @@ inline bool use_small_tiles(int M, int N) {
     return M > 64 && (long long)cdiv(M, 128) * cdiv(N, BN) < thr;
 }
 
+// 256 x 256 tiles (xps_gemm_big.h): bf16 split-product mode, whole tiles only, plain 16-byte aligned operands, and
+// enough tiles to give every CU one.  XPS_GEMM_BIG=0 switches the path off (A/B runs, tests of the small-tile kernels).
+std::atomic<int>& big_switch() {
+    static std::atomic<int> on([] { const char* e = getenv("XPS_GEMM_BIG"); return (e && e[0] == '0') ? 0 : 1; }());
+    return on;
+}
+inline bool big_enabled() { return big_switch().load(std::memory_order_relaxed) != 0 && bf_mode(); }
+inline bool big_plain(const float* p, const RowMap& r, int rows) { return aligned16(p) && r.ld % 4 == 0 && r.rpg >= rows; }
+constexpr int BIG_LDS = (int)sizeof(xps_big::BigStage);
+template <typename Kern>
+inline bool big_prepare(Kern kern) {
+    // once per kernel: allow the 96-KB dynamic LDS block
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) == hipSuccess;
+}
+inline int big_min_tiles() {
+    static const int v = [] { const char* e = getenv("XPS_GEMM_BIG_MIN_TILES"); int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
+    return v;
+}
+
 template <bool AK, bool BK>
 int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& rb, const float* A2, const float* B2, int K2,
                 float* C, const RowMap& rc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st) {
@@ -428,6 +546,17 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
         hipLaunchKernelGGL((gemm_small_kernel<AK, BK>), dim3(cdiv(N, 64)), dim3(1024), 0, st, A, ra, B, rb, A2, B2, K2, C, rc,
                            bias, M, N, K, accumulate, vecB);
         return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (big_enabled() && M % xps_big::TM == 0 && N % xps_big::TN == 0 && K % BKT == 0 && K2 % BKT == 0 && K >= 64 &&
+        (long long)(M / xps_big::TM) * (N / xps_big::TN) >= big_min_tiles() &&
+        big_plain(A, ra, AK ? M : K) && big_plain(B, rb, BK ? N : K) && (!A2 || (big_plain(A2, ra, AK ? M : K2) && big_plain(B2, rb, BK ? N : K2))) &&
+        rc.rpg >= M) {
+        static const bool ready = big_prepare(gemm_big_kernel<AK, BK>);
+        if (ready) {
+            hipLaunchKernelGGL((gemm_big_kernel<AK, BK>), dim3((M / xps_big::TM) * (N / xps_big::TN)), dim3(xps_big::NTHR), BIG_LDS, st,
+                               A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
     }
 #define XPS_LAUNCH_GEMM(MI_, EDGE_, BF_)                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, MI_, EDGE_, BF_>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, \
@@ -494,6 +623,17 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
         vb = vb && map_vec_ok(B[j], rb);
     }
     const int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
+    if (big_enabled() && M % xps_big::TM == 0 && N % xps_big::TN == 0 && K % BKT == 0 && K >= 64 && vb &&
+        (long long)(M / xps_big::TM) * (N / xps_big::TN) * nprob >= big_min_tiles() &&
+        big_plain(A, ra, M) && rb.rpg >= N && rc.rpg >= M) {
+        static const bool ready = big_prepare(gemm_big_nt_multi_kernel);
+        if (ready) {
+            hipLaunchKernelGGL(gemm_big_nt_multi_kernel, dim3((M / xps_big::TM) * (N / xps_big::TN) * nprob), dim3(xps_big::NTHR), BIG_LDS,
+                               (hipStream_t)stream, A, ra.ld, pm, rb.ld, rc.ld, N, K, nprob);
+            XPS_CHECK_LAUNCH();
+            return XPS_OK;
+        }
+    }
 #define XPS_LAUNCH_NTM(MI_, EDGE_, BF_)                                                                                  \
     hipLaunchKernelGGL((gemm_nt_multi_kernel<MI_, EDGE_, BF_>), dim3(cdiv(N, BN) * cdiv(M, 64 * MI_) * nprob), dim3(256), 0,   \
                        (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB)
@@ -570,31 +710,55 @@ extern "C" int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra_, const floa
 }
 
 namespace {
-int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_floats) {
+int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_floats, int big_choice = -1) {
     if (n < 1 || n > TN_MAXP) return -1;
     static const int target_blocks = [] {
         const char* e = getenv("XPS_TN_BLOCKS");
         int v = e ? atoi(e) : 0;
         return v > 0 ? v : 768;
     }();
-    long long tiles_total = 0;
-    for (int i = 0; i < n; ++i) tiles_total += (long long)cdiv(probs[i].M, BM) * cdiv(probs[i].N, BN);
-    g.n = n;
-    int blocks = 0;
-    long long off = 0, out = 0;
+    // problems the 256 x 256 kernel takes (whole tiles, plain aligned operands, a long k range); the others stay on
+    // the 128 x 128 kernel.  Each class shares its own block budget among its problems in proportion to their tiles.
+    const bool big_on = big_choice < 0 ? big_enabled() : big_choice != 0;      // (workspace query: both tilings)
+    bool isbig[TN_MAXP];
+    long long tiles_total = 0, tiles_big_total = 0;
     for (int i = 0; i < n; ++i) {
         const xps_tn_problem& q = probs[i];
         if (!q.A || !q.B || !q.C || q.M < 1 || q.N < 1 || q.K < 0) return -1;
+        const RowMap ra = to_rowmap(&q.ra), rb = to_rowmap(&q.rb);
+        isbig[i] = big_on && q.M % xps_big::TM == 0 && q.N % xps_big::TN == 0 && q.K % BKT == 0 && q.K >= 4096 &&
+                   big_plain(q.A, ra, q.K) && big_plain(q.B, rb, q.K);
+        if (isbig[i]) tiles_big_total += (long long)(q.M / xps_big::TM) * (q.N / xps_big::TN);
+        else tiles_total += (long long)cdiv(q.M, BM) * cdiv(q.N, BN);
+    }
+    // big class: one block per CU and round; k-splits such that the launch is one or two nearly full rounds of 256 blocks
+    int sp_big = 1;
+    if (tiles_big_total > 0) {
+        const int r1 = (int)(256 / tiles_big_total), r2 = (int)(512 / tiles_big_total);
+        sp_big = (r1 >= 1 && r1 * tiles_big_total >= 230) ? r1 : (r2 >= 1 ? r2 : 1);
+    }
+    g.n = n;
+    int blocks = 0, blocks_big = 0;
+    long long off = 0, out = 0;
+    for (int i = 0; i < n; ++i) {
+        const xps_tn_problem& q = probs[i];
         TnProb& P = g.p[i];
         P.A = q.A; P.B = q.B; P.C = q.C; P.colsum = q.colsum_a;
         P.ra = to_rowmap(&q.ra); P.rb = to_rowmap(&q.rb); P.rc = to_rowmap(&q.rc);
         P.M = q.M; P.N = q.N; P.K = q.K; P.accumulate = q.accumulate;
         const int tiles = cdiv(q.M, BM) * cdiv(q.N, BN);
         const long long split_stride = tn_split_stride(tiles, q.M, q.colsum_a != nullptr);   // see gemm_tn_grouped_kernel
-        // share the block budget among the problems in proportion to their tiles; >= 64 rows per split
-        int want = (int)((target_blocks * (long long)tiles / (tiles_total > 0 ? tiles_total : 1) + tiles - 1) / tiles);
-        int maxs = cdiv(q.K > 0 ? q.K : 1, 64);
-        int sp = want < maxs ? want : maxs;
+        int sp;
+        if (isbig[i]) {
+            sp = sp_big;
+            const int maxs = q.K / 512;                              // >= 512 k rows per split
+            if (sp > maxs) sp = maxs;
+        } else {
+            // share the block budget among the problems in proportion to their tiles; >= 64 rows per split
+            int want = (int)((target_blocks * (long long)tiles / (tiles_total > 0 ? tiles_total : 1) + tiles - 1) / tiles);
+            int maxs = cdiv(q.K > 0 ? q.K : 1, 64);
+            sp = want < maxs ? want : maxs;
+        }
         if (sp < 1) sp = 1;
         if (sp > 256) sp = 256;
         P.splits = sp;
@@ -603,12 +767,18 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         P.vecA = (int)map_vec_ok(q.A, P.ra);
         P.vecB = (int)map_vec_ok(q.B, P.rb);
         P.slab_off = off;
-        P.block_start = blocks;
-        P.pad_ = 0;
-        blocks += tiles * sp;
+        P.big = isbig[i] ? 1 : 0;
+        if (isbig[i]) {
+            P.block_start = blocks_big;
+            blocks_big += (q.M / xps_big::TM) * (q.N / xps_big::TN) * sp;
+        } else {
+            P.block_start = blocks;
+            blocks += tiles * sp;
+        }
         off += (long long)sp * split_stride;
         out += split_stride;
     }
+    g.total_blocks_big = blocks_big;
     g.total_blocks = blocks;
     g.total_out = out;
     ws_floats = (size_t)off;
@@ -620,7 +790,7 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
     // opt-in (XPS_TN_UNIFORM=1): measured twice (rounds 1 and 2, cfg-2 layer-1 group) -- same launch time (151 vs 152 us) and
     // the same fabric traffic within 1 %: co-resident blocks drift apart by more k-tiles than an XCD's L2 holds
     static const bool allow = [] { const char* e = getenv("XPS_TN_UNIFORM"); return e && e[0] == '1'; }();
-    if (same_k && allow && probs[0].K > 0) {
+    if (same_k && allow && probs[0].K > 0 && blocks_big == 0) {
         int sp = (int)((target_blocks + tiles_total - 1) / tiles_total);
         const int maxs = cdiv(probs[0].K, 64);
         if (sp > maxs) sp = maxs;
@@ -651,10 +821,11 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
 }  // namespace
 
 extern "C" size_t xps_gemm_tn_grouped_f32_workspace(const xps_tn_problem* probs, int n) {
+    // the larger of both tilings: the size must not depend on the precision mode / tile switch at launch time
     TnGroup g;
-    size_t fl = 0;
-    if (!probs || build_group(probs, n, g, fl)) return 0;
-    return fl * sizeof(float) + 16;
+    size_t fl0 = 0, fl1 = 0;
+    if (!probs || build_group(probs, n, g, fl0, 0) || build_group(probs, n, g, fl1, 1)) return 0;
+    return (fl0 > fl1 ? fl0 : fl1) * sizeof(float) + 16;
 }
 
 extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void* workspace, size_t workspace_bytes,
@@ -671,9 +842,20 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
         return XPS_E_WORKSPACE;
     }
     bool edge = false;
-    for (int i = 0; i < n; ++i) edge = edge || (probs[i].M % BM) || (probs[i].N % BN);
+    for (int i = 0; i < n; ++i) edge = edge || (!g.p[i].big && ((probs[i].M % BM) || (probs[i].N % BN)));
     const bool bf = bf_mode();
-    if (bf && edge)
+    if (g.total_blocks_big > 0) {
+        static const bool ready = big_prepare(gemm_big_tn_kernel);
+        if (!ready) {
+            xps_set_error("xps_gemm_tn_grouped_f32: cannot reserve %d bytes of LDS", BIG_LDS);
+            return XPS_E_HIP;
+        }
+        hipLaunchKernelGGL(gemm_big_tn_kernel, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS, (hipStream_t)stream, g,
+                           (float*)workspace);
+        XPS_CHECK_LAUNCH();
+    }
+    if (g.total_blocks == 0) {
+    } else if (bf && edge)
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     else if (bf)
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
@@ -697,6 +879,14 @@ extern "C" int xps_set_gemm_precision(int mode) {
 }
 
 extern "C" int xps_get_gemm_precision(void) { return gemm_mode().load(); }
+
+extern "C" int xps_set_gemm_big_tiles(int on) {
+    XPS_CHECK_ARG(on == 0 || on == 1, "on: 0 = 128 x 128 tiles only, 1 = 256 x 256 tiles for large interior shapes");
+    big_switch().store(on);
+    return XPS_OK;
+}
+
+extern "C" int xps_get_gemm_big_tiles(void) { return big_switch().load(); }
 
 #ifdef XPS_GSTAMP
 extern "C" int xps_debug_read_gstamps(unsigned long long* host, int n) {

@@ -1,0 +1,168 @@
+// 256 x 256 output tiles on 8 waves (512 threads): the bf16 split-product pipeline of xps_gemm_tile.h for LARGE interior
+// shapes (the configs[3] layer GEMMs: 40960 x 1536 x 1024 projections, 40960 x 1024 x 3072 input gradients, 1536 x 1024 x
+// 40960 weight gradients).  Same arithmetic as the 128 x 128 kernels -- operands split hi + lo while they are staged, per
+// 32 x 32 accumulator tile and k-tile the products lo*hi, hi*lo, hi*hi in that order -- so a product whose k range is not
+// split differently has the same bits as from the small-tile kernels.
+//
+// Why a second tile shape: the split costs ~12 issue cycles per staged element and a wave has 24 free issue cycles per
+// v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md, cycle constants).  Staged elements per MFMA go with (BM + BN) / (BM BN),
+// fragment reads per MFMA with (WM + WN) / (WM WN): 128 x 128 blocks of 64 x 64 wave tiles spend ~27 issue cycles per
+// MFMA beside the MFMA itself (issue-bound: 0.30 of the bf16 peak measured on 8192^3), 256 x 256 blocks of 128 x 64 wave
+// tiles ~15.  One block per CU (96 KB of LDS, 2 waves per SIMD at <= 256 registers).
+//
+// Preconditions (checked on the host, see big_ok): M % 256 == 0, N % 256 == 0, every k range a multiple of 16, plain
+// leading dimensions (no row groups), 16-byte aligned operands.
+#pragma once
+#include "xps_gemm_tile.h"
+
+namespace xps_big {
+using namespace xps_tile;
+
+constexpr int TM = 256, TN = 256, NTHR = 512;
+
+struct BigStage {
+    BfTile<256> a[2];
+    BfTile<256> b[2];
+};
+
+// thread -> two 16-byte vectors of a 256 x 16 k-tile.  KC ([x][k]): row x = tid / 4 + 128 r, k = 4 (tid % 4);
+// !KC ([k][x]): k row = tid / 64 + 8 r (one wave reads one 1-KiB row), x = 4 (tid % 64)
+template <bool KC>
+struct BigLoader {
+    const float* p[2];
+    long long kstep;
+    __device__ inline void init(const float* __restrict__ P, long long ld, int x0, int k0, int tid) {
+        if (KC) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) p[r] = P + (long long)(x0 + (tid >> 2) + 128 * r) * ld + k0 + (tid & 3) * 4;
+            kstep = BKT;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) p[r] = P + (long long)(k0 + (tid >> 6) + 8 * r) * ld + x0 + (tid & 63) * 4;
+            kstep = (long long)BKT * ld;
+        }
+    }
+    __device__ inline void load(f32x4 (&v)[2], int kt) const {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) v[r] = *reinterpret_cast<const f32x4*>(p[r] + kt * kstep);
+    }
+};
+
+template <bool KC>
+__device__ inline void big_stage(const f32x4 (&v)[2], BfTile<256>& S, int tid) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+        if (KC) {
+            const int x = (tid >> 2) + 128 * r, k4 = (tid & 3) * 4;
+            *reinterpret_cast<bf16x4*>(&S.hi[x][k4]) = h;
+            *reinterpret_cast<bf16x4*>(&S.lo[x][k4]) = l;
+        } else {
+            const int k = (tid >> 6) + 8 * r, x4 = (tid & 63) * 4;
+            *reinterpret_cast<bf16x4*>(&S.thi[k][x4]) = h;
+            *reinterpret_cast<bf16x4*>(&S.tlo[k][x4]) = l;
+        }
+    }
+}
+
+// Accumulates nkt k-tiles.  acc[i][j]: rows wm + 32 i, columns wn + 32 j of the block tile, wave w -> wm = 128 (w / 4),
+// wn = 64 (w % 4); C/D layout of the 32 x 32 MFMA.  csum (want_csum, [k][x] A operands only): running sums of this
+// thread's 4 x columns over its k rows (the bias gradient of the weight-gradient form), taken from the staging registers.
+template <bool AK, bool BK>
+__device__ inline void big_pipeline(f32x16 (&acc)[4][2], f32x4& csum, const bool want_csum, const BigLoader<AK>& la,
+                                    const BigLoader<BK>& lb, const int nkt, BigStage& S) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    f32x4 ra0[2], rb0[2], ra1[2], rb1[2];                 // k-tiles kt + 1 and kt + 2 in flight
+    if (nkt > 0) {
+        la.load(ra0, 0); lb.load(rb0, 0);
+        if (nkt > 1) { la.load(ra1, 1); lb.load(rb1, 1); }
+        big_stage<AK>(ra0, S.a[0], tid);
+        big_stage<BK>(rb0, S.b[0], tid);
+        if (!AK && want_csum) csum += ra0[0] + ra0[1];
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 2 < nkt) { la.load(ra0, kt + 2); lb.load(rb0, kt + 2); }
+        {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf_frag<BK, 256>(S.b[buf], wn + j * 32, lane, bh[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x8 ah, al;
+                bf_frag<AK, 256>(S.a[buf], wm + i * 32, lane, ah, al);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nkt) {
+            big_stage<AK>(ra1, S.a[buf ^ 1], tid);
+            big_stage<BK>(rb1, S.b[buf ^ 1], tid);
+            if (!AK && want_csum) csum += ra1[0] + ra1[1];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { ra1[r] = ra0[r]; rb1[r] = rb0[r]; }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ inline void big_zero(f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// C tile store (plain leading dimension): a store instruction writes 2 rows x 32 consecutive floats per wave
+__device__ inline void big_store_c(const f32x16 (&acc)[4][2], float* __restrict__ C, long long ldc, const float* __restrict__ bias,
+                                   int m0, int n0, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int li = lane & 31, lk = lane >> 5;
+    float* cbase = C + (long long)(m0 + wm + 4 * lk) * ldc + n0 + wn + li;
+    float bv[2] = {0.f, 0.f};
+    if (bias) { bv[0] = bias[n0 + wn + li]; bv[1] = bias[n0 + wn + 32 + li]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* crow = cbase + (long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v = acc[i][j][r] + bv[j];
+                if (accumulate) v += crow[j * 32];
+                __builtin_nontemporal_store(v, &crow[j * 32]);
+            }
+        }
+}
+
+// Split-K slab of a 256 x 256 tile, written as its four 128 x 128 sub-tiles in the register order of the small-tile
+// kernels (xps_gemm.hip: slab_store / slab_decode), so that ONE reduce kernel serves both tile shapes: sub-tile
+// (wave / 4, (wave % 4) / 2), its "wave" = 2 (i / 2) + wave % 2, its accumulator tile (i % 2, j).
+// sub[] = the four sub-tiles' slab addresses (row-major 2 x 2).
+__device__ inline void big_slab_store(const f32x16 (&acc)[4][2], float* const (&sub)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* base = sub[(wave >> 2) * 2 + ((wave & 3) >> 1)] + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                const int wave_o = (i >> 1) * 2 + (wave & 1);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + wave_o * 4096 + (((i & 1) * 2 + j) * 4 + q) * 256));
+            }
+}
+
+}  // namespace xps_big

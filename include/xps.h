@@ -61,6 +61,12 @@ int xps_stream_destroy(void* stream);
  * XPS_GEMM_PRECISION=fp32|bf16x3; returns XPS_E_INVALID for other modes. */
 int xps_set_gemm_precision(int mode);
 int xps_get_gemm_precision(void);
+/* Tile shape of the matrix kernels in bf16x3 mode: 1 (default; XPS_GEMM_BIG=0 in the environment starts with 0) lets large
+ * interior shapes (M, N multiples of 256, k ranges multiples of 16, plain 16-byte aligned operands, >= 192 tiles) run on
+ * 256 x 256 tiles / 8 waves; 0 keeps every product on the 128 x 128 (64 x 128) tiles.  Same arithmetic per k-tile in both:
+ * products whose k range is not split (nt / nn / nn2 / nt_multi) have the same bits either way. */
+int xps_set_gemm_big_tiles(int on);
+int xps_get_gemm_big_tiles(void);
 
 /* ------------------------------------------------------------------------- */
 /* Dense fp32 contractions: bf16 split products (default) or the f32-input     */

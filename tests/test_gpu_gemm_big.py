@@ -1,0 +1,169 @@
+"""GPU tests of the 256 x 256-tile GEMM kernels (csrc/xps_gemm_big.h; the large layer products of configs[3]: input
+projections nn_models/models.py:687 (x W_ih^T inside torch.nn.GRU), their input and weight gradients).  The products
+whose k range is not split must equal the 128 x 128-tile kernels BIT FOR BIT (same split arithmetic, same order per
+accumulator); every form is bounded against fp64 by the split-product error model of DESIGN.md 4.0."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cross_patient_speech_decoding_amd import _build  # noqa: E402
+from cross_patient_speech_decoding_amd._lib import call, lib, rowmap  # noqa: E402
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _built():
+    _build.build(verbose=False)
+    assert torch.cuda.is_available(), 'gpu tests need the MI355X'
+
+
+def XF():
+    from cross_patient_speech_decoding_amd.nn_models import functional
+    return functional
+
+
+@pytest.fixture
+def tiles():
+    """tiles(0 | 1): 128 x 128 tiles only / 256 x 256 where eligible; restores the setting, bf16x3 mode for the test."""
+    l = lib()
+    old_t, old_p = l.xps_get_gemm_big_tiles(), l.xps_get_gemm_precision()
+    l.xps_set_gemm_precision(1)
+    yield l.xps_set_gemm_big_tiles
+    l.xps_set_gemm_big_tiles(old_t)
+    l.xps_set_gemm_precision(old_p)
+
+
+def _bound(a64, b64_t):
+    """1.6e-5 * sum_k |a||b| for a (M, K) @ b_t (K, N)"""
+    return 1.6e-5 * (a64.abs() @ b64_t.abs())
+
+
+M0, N0 = 4096, 3072          # 16 x 12 = 192 tiles of 256 x 256: the smallest grid the dispatcher sends to the big kernels
+
+
+@pytest.mark.parametrize('K,bias,acc', [(64, True, False), (208, False, True), (1024, True, True)])
+def test_nt_equals_small_tiles_bitwise_and_fp64(K, bias, acc, tiles):
+    xf = XF()
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn(M0, K, generator=g).cuda(); B = torch.randn(N0, K, generator=g).cuda()
+    bv = torch.randn(N0, generator=g).cuda() if bias else None
+    C0 = torch.randn(M0, N0, generator=g).cuda()
+    outs = []
+    for t in (0, 1):
+        tiles(t)
+        Cc = C0.clone()
+        xf.gemm_nt(A, B, Cc, M0, N0, K, bias=bv, accumulate=acc)
+        outs.append(Cc)
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double() @ B.double().T + (bv.double() if bias else 0) + (C0.double() if acc else 0)
+    err = (outs[1].double() - ref).abs()
+    assert bool((err <= _bound(A.double(), B.double().T) + 1e-6 * ref.abs() + 1e-6).all()), float(err.max())
+
+
+def test_big_kernels_are_selected_for_the_north_star_products(tiles):
+    """Guards the dispatch conditions: with the switch on, a qualifying product must NOT equal a run whose k order differs
+    ... it cannot be observed from outside bitwise (same bits by design), so time both settings instead: the 256-tile
+    launch of an 8192 x 4096 x 2048 product is well over 15 % faster."""
+    xf = XF()
+    M, N, K = 8192, 4096, 2048
+    A = torch.randn(M, K, device='cuda'); B = torch.randn(N, K, device='cuda'); Cc = torch.empty(M, N, device='cuda')
+    times = []
+    for t in (0, 1):
+        tiles(t)
+        for _ in range(3):
+            xf.gemm_nt(A, B, Cc, M, N, K)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            xf.gemm_nt(A, B, Cc, M, N, K)
+        e1.record(); torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / 10)
+    assert times[1] < 0.85 * times[0], times
+
+
+def test_nn_and_nn2_equal_small_tiles_bitwise(tiles):
+    """input-gradient forms: A [m][k] times B [k][n]; nn2 sums two operand pairs (both directions) in registers"""
+    xf = XF()
+    g = torch.Generator().manual_seed(7)
+    K1, K2 = 96, 160
+    A1 = torch.randn(M0, K1, generator=g).cuda(); B1 = torch.randn(K1, N0, generator=g).cuda()
+    A2 = torch.randn(M0, K1, generator=g).cuda(); B2 = torch.randn(K1, N0, generator=g).cuda()
+    outs = []
+    for t in (0, 1):
+        tiles(t)
+        c1 = torch.empty(M0, N0, device='cuda'); c2 = torch.empty(M0, N0, device='cuda')
+        xf.gemm_nn(A1, B1, c1, M0, N0, K1)
+        ra, rb, rc = rowmap(K1), rowmap(N0), rowmap(N0)
+        call('xps_gemm_nn2_f32', xf._ptr(A1), xf._ptr(B1), K1, xf._ptr(A2), xf._ptr(B2), K1, C.byref(ra), C.byref(rb), xf._ptr(c2),
+             C.byref(rc), M0, N0, 0, xf._stream())
+        outs.append((c1, c2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = A1.double() @ B1.double() + A2.double() @ B2.double()
+    bound = _bound(A1.double(), B1.double()) + _bound(A2.double(), B2.double())
+    assert bool(((outs[1][1].double() - ref).abs() <= bound + 1e-6).all())
+    del K2
+
+
+def test_nt_multi_equals_small_tiles_bitwise(tiles):
+    """the input projections of both directions in one launch (GRULayerFn.forward)"""
+    xf = XF()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 4096, 1536, 112
+    A = torch.randn(M, K, generator=g).cuda()
+    Bs = [torch.randn(N, K, generator=g).cuda() for _ in range(2)]
+    bs = [torch.randn(N, generator=g).cuda() for _ in range(2)]
+    outs = []
+    for t in (0, 1):
+        tiles(t)
+        Cs = [torch.empty(M, N, device='cuda') for _ in range(2)]
+        ra, rb, rc = rowmap(K), rowmap(K), rowmap(N)
+        call('xps_gemm_nt_multi_f32', xf._ptr(A), C.byref(ra), xf._ptr_array(Bs), C.byref(rb), xf._ptr_array(Cs), C.byref(rc),
+             xf._ptr_array(bs), 2, M, N, K, xf._stream())
+        outs.append(Cs)
+    for d in range(2):
+        assert torch.equal(outs[0][d], outs[1][d])
+        ref = A.double() @ Bs[d].double().T + bs[d].double()
+        assert bool(((outs[1][d].double() - ref).abs() <= _bound(A.double(), Bs[d].double().T) + 1e-6).all())
+
+
+def test_weight_gradient_group_mixes_both_tile_shapes(tiles):
+    """One grouped launch with problems for the 256-tile kernel (M, N multiples of 256), for the 128-tile kernel (an edge
+    shape) and column sums / accumulate flags on both: every output against fp64, and against the all-small-tile run."""
+    xf = XF()
+    g = torch.Generator().manual_seed(13)
+    K = 8192
+    ld = 1024
+    dgi = torch.randn(K, 1536, generator=g).cuda()
+    x = torch.randn(K, ld, generator=g).cuda()
+    xs = torch.randn(K, 100, generator=g).cuda()
+
+    def run():
+        dw_a = torch.zeros(1024, 512, device='cuda'); db_a = torch.zeros(1536, device='cuda')      # r,z rows of a dW_hh + its bias
+        dw_b = torch.ones(1536, 1024, device='cuda'); db_b = torch.ones(1536, device='cuda')       # dW_ih, accumulate
+        dw_c = torch.zeros(1536, 100, device='cuda')                                               # edge shape: small tiles
+        probs = [xf.tn_problem(dgi, x[:, 512:], dw_a, 1024, 512, K, ra=rowmap(1536), rb=rowmap(ld), rc=rowmap(512), colsum_out=db_a),
+                 xf.tn_problem(dgi, x, dw_b, 1536, 1024, K, colsum_out=db_b, accumulate=True),
+                 xf.tn_problem(dgi, xs, dw_c, 1536, 100, K)]
+        keep = xf.gemm_tn_grouped(probs, dgi.device)
+        torch.cuda.synchronize()
+        del keep
+        return dw_a, db_a, dw_b, db_b, dw_c
+
+    tiles(0); small = run()
+    tiles(1); big = run()
+    d64, x64 = dgi.double(), x.double()
+    refs = [d64[:, :1024].T @ x64[:, 512:], d64.sum(0)[:1024], 1 + d64.T @ x64, 1 + d64.sum(0), d64.T @ xs.double()]
+    bounds = [_bound(d64[:, :1024].T, x64[:, 512:]), 1e-6 * d64.abs().sum(0)[:1024], _bound(d64.T, x64), 1e-6 * d64.abs().sum(0),
+              _bound(d64.T, xs.double())]
+    for name, b, s, r, bd in zip(['dw_a', 'db_a', 'dw_b', 'db_b', 'dw_c'], big, small, refs, bounds):
+        if name == 'db_a':
+            b, s = b[:1024], s[:1024]
+        err = (b.double() - r).abs()
+        assert bool((err <= bd + 1e-5).all()), (name, float(err.max()))
+        assert float((b - s).abs().max()) <= 2 * float(bd.max()) + 1e-5, name
+    again = run()
+    for b, a in zip(big, again):
+        assert torch.equal(b, a)                       # deterministic
