@@ -348,6 +348,37 @@ def test_eigh_sym_top_indefinite_matrix():
         assert np.abs(C @ V - V * w).max() <= 1e-10 * np.abs(wr).max()
 
 
+@pytest.mark.parametrize('n,k,kind', [(512, 10, 'mcca'), (1024, 30, 'mcca'), (600, 20, 'random'), (512, 12, 'clustered')])
+def test_eigh_sym_top_subspace_iteration(n, k, kind):
+    """Large n, few pairs: the Chebyshev-filtered subspace iteration (not the full Jacobi) must give the pairs LAPACK gives --
+    MCCA-like spectra (a few large generalised correlations over a bulk, negative tail), a random indefinite matrix (small
+    gaps) and a cluster of equal eigenvalues straddling position k."""
+    la = LA()
+    rng = np.random.default_rng(n + k)
+    if kind == 'mcca':
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.concatenate([np.linspace(6.5, 2.0, k + 5), rng.uniform(-1.0, 1.2, n - k - 5)])
+        C = (Q * lam) @ Q.T
+    elif kind == 'random':
+        A = rng.standard_normal((n, n))
+        C = A + A.T
+    else:
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.concatenate([np.linspace(9.0, 5.0, k - 3), np.full(6, 4.0), rng.uniform(-2.0, 3.0, n - k - 3)])
+        C = (Q * lam) @ Q.T
+    C = 0.5 * (C + C.T)
+    st = {}
+    w, V = la.eigh_sym_top(torch.from_numpy(C).cuda(), k, stats=st)
+    assert 'outer' in st and not st.get('fallback'), f'the subspace path did not run / converge: {st}'
+    wr = np.linalg.eigvalsh(C)[::-1]
+    scale = np.abs(wr).max()
+    np.testing.assert_allclose(w, wr[:k], atol=1e-11 * scale)
+    assert np.abs(C @ V - V * w).max() <= 1e-11 * scale
+    np.testing.assert_allclose(V.T @ V, np.eye(k), atol=1e-11)
+    w2, V2 = la.eigh_sym_top(torch.from_numpy(C).cuda(), k)
+    assert np.array_equal(w, w2) and np.array_equal(V, V2)          # reproducible run to run
+
+
 def test_device_resident_inputs_stay_on_the_device(golden_dir):
     """A device tensor in -> a device tensor out (no PCIe round trip between alignment stages), same values as the ndarray path."""
     g = _load(golden_dir, 'align_cca.npz')
