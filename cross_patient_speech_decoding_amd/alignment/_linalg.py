@@ -347,13 +347,14 @@ def eigh_sym_top(C, k, tol=2e-14, max_outer=40, max_degree=40, stats=None):
     and the operator moves their eigenvalues to the lower bound (C - L (Theta - lo) L^T), so that a well separated
     group of large eigenvalues (the shared latents of MCCA: 15 against a bulk below 2.1) does not cap the degree that
     the pairs inside the bulk need.  The degree adapts to an amplification of <= 2e7 per outer step across the block.
-    Small problems (n <= 256) and wide requests (block over 128 columns or over n / 3) take the full decomposition,
+    Small problems (n <= 640) and wide requests (block over 128 columns or over n / 3) take the full decomposition,
     and so does any run that loses rank or does not converge.  ``stats``: receives iteration counts."""
     C = C.to(F64).contiguous()
     n = C.shape[0]
     k = min(k, n)
     m = k + max(8, (k + 1) // 2)
-    if n <= 256 or m > 128 or 3 * m > n or not lib().xps_jacobi_small_supported(m, m, 0):
+    # the full Jacobi costs ~73 ms x (n / 1024)^3, the subspace iteration 9-35 ms almost independent of n: worth it above ~640
+    if n <= 640 or m > 128 or 3 * m > n or not lib().xps_jacobi_small_supported(m, m, 0):
         return _eigh_sym_top_full(C, k)
     dev = C.device
     bounds = _lanczos_bounds(C)

@@ -368,35 +368,47 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
 extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
 
 // C (+)= A B (+ A2 B2) + bias, plain leading dimensions.  1-D grid, logical order (m-tile, n-tile).
-template <bool AK, bool BK>
+// DEEP: 32-deep LDS stages (k ranges multiples of 32), see xps_gemm_big.h
+template <bool AK, bool BK, bool DEEP>
+__device__ inline void big_accumulate(f32x16 (&acc)[4][2], f32x4& csum, bool want_csum, const float* __restrict__ A, long long lda,
+                                      const float* __restrict__ B, long long ldb, int m0, int n0, int kbeg, int kend) {
+    if constexpr (DEEP) {
+        xps_big::BigStage32& st = *reinterpret_cast<xps_big::BigStage32*>(big_smem);
+        xps_big::BigLoader32<AK> la;
+        xps_big::BigLoader32<BK> lb;
+        la.init(A, lda, m0, kbeg, threadIdx.x);
+        lb.init(B, ldb, n0, kbeg, threadIdx.x);
+        xps_big::big_pipeline32<AK, BK>(acc, csum, want_csum, la, lb, (kend - kbeg) / 32, st);
+    } else {
+        xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
+        xps_big::BigLoader<AK> la;
+        xps_big::BigLoader<BK> lb;
+        la.init(A, lda, m0, kbeg, threadIdx.x);
+        lb.init(B, ldb, n0, kbeg, threadIdx.x);
+        xps_big::big_pipeline<AK, BK>(acc, csum, want_csum, la, lb, (kend - kbeg) / BKT, st);
+    }
+}
+
+template <bool AK, bool BK, bool DEEP>
 __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                            long long ldb, const float* __restrict__ A2, const float* __restrict__ B2,
                                                            int K2, float* __restrict__ C, long long ldc,
                                                            const float* __restrict__ bias, int N, int K, int accumulate) {
-    xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
     const int tiles_n = N / xps_big::TN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * xps_big::TM, n0 = (lid % tiles_n) * xps_big::TN;
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
-    xps_big::BigLoader<AK> la;
-    xps_big::BigLoader<BK> lb;
-    la.init(A, lda, m0, 0, threadIdx.x);
-    lb.init(B, ldb, n0, 0, threadIdx.x);
-    xps_big::big_pipeline<AK, BK>(acc, nocs, false, la, lb, K / BKT, st);
-    if (A2) {
-        la.init(A2, lda, m0, 0, threadIdx.x);
-        lb.init(B2, ldb, n0, 0, threadIdx.x);
-        xps_big::big_pipeline<AK, BK>(acc, nocs, false, la, lb, K2 / BKT, st);
-    }
+    big_accumulate<AK, BK, DEEP>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K);
+    if (A2) big_accumulate<AK, BK, DEEP>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2);
     xps_big::big_store_c(acc, C, ldc, bias, m0, n0, accumulate);
 }
 
 // same A, up to 4 (B, bias, C): logical order (m-tile, problem, n-tile)
+template <bool DEEP>
 __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* __restrict__ A, long long lda, NtMulti pm, long long ldb,
                                                                     long long ldc, int N, int K, int nprob) {
-    xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
     const int tiles_n = N / xps_big::TN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int per_m = nprob * tiles_n, rem = lid % per_m;
@@ -405,17 +417,14 @@ __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* 
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
-    xps_big::BigLoader<true> la, lb;
-    la.init(A, lda, m0, 0, threadIdx.x);
-    lb.init(pm.B[z], ldb, n0, 0, threadIdx.x);
-    xps_big::big_pipeline<true, true>(acc, nocs, false, la, lb, K / BKT, st);
+    big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K);
     xps_big::big_store_c(acc, pm.C[z], ldc, pm.bias[z], m0, n0, 0);
 }
 
 // grouped weight gradients: the problems of a TnGroup marked `big`; block = (problem, k-split, 256 x 256 tile); slabs in
 // the layout of the 128 x 128 kernel (four sub-tiles per block) so that gemm_tn_grouped_reduce serves both launches
+template <bool DEEP>
 __global__ __launch_bounds__(512, 1) void gemm_big_tn_kernel(TnGroup g, float* __restrict__ ws) {
-    xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int pi = -1;
 #pragma unroll 1
@@ -434,10 +443,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_tn_kernel(TnGroup g, float* _
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    xps_big::BigLoader<false> la, lb;
-    la.init(P.A, P.ra.ld, tm * xps_big::TM, kbeg, threadIdx.x);
-    lb.init(P.B, P.rb.ld, tn * xps_big::TN, kbeg, threadIdx.x);
-    xps_big::big_pipeline<false, false>(acc, csum, want_cs, la, lb, (kend - kbeg) / BKT, st);
+    big_accumulate<false, false, DEEP>(acc, csum, want_cs, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, kend);
     float* sub[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -525,11 +531,18 @@ std::atomic<int>& big_switch() {
 }
 inline bool big_enabled() { return big_switch().load(std::memory_order_relaxed) != 0 && bf_mode(); }
 inline bool big_plain(const float* p, const RowMap& r, int rows) { return aligned16(p) && r.ld % 4 == 0 && r.rpg >= rows; }
-constexpr int BIG_LDS = (int)sizeof(xps_big::BigStage);
+constexpr int BIG_LDS = (int)sizeof(xps_big::BigStage), BIG_LDS32 = (int)sizeof(xps_big::BigStage32);
 template <typename Kern>
-inline bool big_prepare(Kern kern) {
-    // once per kernel: allow the 96-KB dynamic LDS block
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS) == hipSuccess;
+inline bool big_prepare(Kern kern, int bytes) {
+    // once per kernel: allow the 96- / 144-KB dynamic LDS block
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+// 32-deep stages (opt-in: XPS_GEMM_BIG_DEEP=1, and only where every k range is a multiple of 32).  Measured: the single
+// launches gain (projection 418 -> 396 us, input gradient 423 -> 392 us, 8192^3 0.40 -> 0.45 of peak; the TN form loses
+// 1-5 %), the configs[3] step does not (8.26-8.27 vs 8.20-8.23 ms, A/B on one box): 16-deep stays the default.
+inline bool big_deep_allowed() {
+    static const bool on = [] { const char* e = getenv("XPS_GEMM_BIG_DEEP"); return e && e[0] == '1'; }();
+    return on;
 }
 inline int big_min_tiles() {
     static const int v = [] { const char* e = getenv("XPS_GEMM_BIG_MIN_TILES"); int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
@@ -551,10 +564,15 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
         (long long)(M / xps_big::TM) * (N / xps_big::TN) >= big_min_tiles() &&
         big_plain(A, ra, AK ? M : K) && big_plain(B, rb, BK ? N : K) && (!A2 || (big_plain(A2, ra, AK ? M : K2) && big_plain(B2, rb, BK ? N : K2))) &&
         rc.rpg >= M) {
-        static const bool ready = big_prepare(gemm_big_kernel<AK, BK>);
+        static const bool ready = big_prepare(gemm_big_kernel<AK, BK, false>, BIG_LDS) && big_prepare(gemm_big_kernel<AK, BK, true>, BIG_LDS32);
         if (ready) {
-            hipLaunchKernelGGL((gemm_big_kernel<AK, BK>), dim3((M / xps_big::TM) * (N / xps_big::TN)), dim3(xps_big::NTHR), BIG_LDS, st,
-                               A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate);
+            const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN));
+            if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0)
+                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, true>), bgrid, dim3(xps_big::NTHR), BIG_LDS32, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate);
+            else
+                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate);
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
     }
@@ -626,9 +644,14 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
     if (big_enabled() && M % xps_big::TM == 0 && N % xps_big::TN == 0 && K % BKT == 0 && K >= 64 && vb &&
         (long long)(M / xps_big::TM) * (N / xps_big::TN) * nprob >= big_min_tiles() &&
         big_plain(A, ra, M) && rb.rpg >= N && rc.rpg >= M) {
-        static const bool ready = big_prepare(gemm_big_nt_multi_kernel);
+        static const bool ready = big_prepare(gemm_big_nt_multi_kernel<false>, BIG_LDS) && big_prepare(gemm_big_nt_multi_kernel<true>, BIG_LDS32);
         if (ready) {
-            hipLaunchKernelGGL(gemm_big_nt_multi_kernel, dim3((M / xps_big::TM) * (N / xps_big::TN) * nprob), dim3(xps_big::NTHR), BIG_LDS,
+            const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN) * nprob);
+            if (big_deep_allowed() && K % 32 == 0)
+                hipLaunchKernelGGL(gemm_big_nt_multi_kernel<true>, bgrid, dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, A, ra.ld, pm,
+                                   rb.ld, rc.ld, N, K, nprob);
+            else
+                hipLaunchKernelGGL(gemm_big_nt_multi_kernel<false>, bgrid, dim3(xps_big::NTHR), BIG_LDS,
                                (hipStream_t)stream, A, ra.ld, pm, rb.ld, rc.ld, N, K, nprob);
             XPS_CHECK_LAUNCH();
             return XPS_OK;
@@ -762,7 +785,8 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         if (sp < 1) sp = 1;
         if (sp > 256) sp = 256;
         P.splits = sp;
-        P.kchunk = ((cdiv(q.K > 0 ? q.K : 1, sp) + BKT - 1) / BKT) * BKT;
+        const int kq = (isbig[i] && q.K % 32 == 0) ? 32 : BKT;             // (32-deep stages of the big-tile kernel)
+        P.kchunk = ((cdiv(q.K > 0 ? q.K : 1, sp) + kq - 1) / kq) * kq;
         P.tiles_n = cdiv(q.N, BN);
         P.vecA = (int)map_vec_ok(q.A, P.ra);
         P.vecB = (int)map_vec_ok(q.B, P.rb);
@@ -845,12 +869,21 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     for (int i = 0; i < n; ++i) edge = edge || (!g.p[i].big && ((probs[i].M % BM) || (probs[i].N % BN)));
     const bool bf = bf_mode();
     if (g.total_blocks_big > 0) {
-        static const bool ready = big_prepare(gemm_big_tn_kernel);
+        static const bool ready = big_prepare(gemm_big_tn_kernel<false>, BIG_LDS) && big_prepare(gemm_big_tn_kernel<true>, BIG_LDS32);
         if (!ready) {
-            xps_set_error("xps_gemm_tn_grouped_f32: cannot reserve %d bytes of LDS", BIG_LDS);
+            xps_set_error("xps_gemm_tn_grouped_f32: cannot reserve %d bytes of LDS", BIG_LDS32);
             return XPS_E_HIP;
         }
-        hipLaunchKernelGGL(gemm_big_tn_kernel, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS, (hipStream_t)stream, g,
+        // measured: the [k][x] x [k][x] form gains nothing from 32-deep stages (its fetches are full lines already) and loses
+        // 1-5 % to the larger LDS block: 16-deep unless XPS_GEMM_BIG_DEEP_TN=1
+        static const bool deep_tn = [] { const char* e = getenv("XPS_GEMM_BIG_DEEP_TN"); return e && e[0] == '1'; }();
+        bool deep = big_deep_allowed() && deep_tn;
+        for (int i = 0; i < n; ++i) deep = deep && (!g.p[i].big || (g.p[i].kchunk % 32 == 0 && g.p[i].K % 32 == 0));
+        if (deep)
+            hipLaunchKernelGGL(gemm_big_tn_kernel<true>, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, g,
+                               (float*)workspace);
+        else
+            hipLaunchKernelGGL(gemm_big_tn_kernel<false>, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS, (hipStream_t)stream, g,
                            (float*)workspace);
         XPS_CHECK_LAUNCH();
     }

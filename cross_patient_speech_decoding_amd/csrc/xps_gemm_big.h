@@ -114,6 +114,159 @@ __device__ inline void big_pipeline(f32x16 (&acc)[4][2], f32x4& csum, const bool
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 32-deep stages (k ranges that are multiples of 32).  What it changes against the 16-deep pipeline above: [x][k]
+// operands are fetched in FULL 128-byte lines (8 lanes x 16 B per row; 16-deep k-tiles took half a line per visit and the
+// other half one k-tile later, from L2 again), and a barrier guards 48 MFMAs per wave instead of 24.  LDS: an [x][k] operand
+// keeps its two 16-deep k-tiles as two swizzled images without padding (hi / lo: 256 rows x 32 B; 16-byte chunk kh of row r
+// sits at chunk kh ^ ((r >> 3) & 1): the b128 fragment reads of a 16-lane group {0-3, 12-15, 20-27}, ... touch 16 distinct
+// 4-bank groups; the second k-tile's image starts 64 B late so that the 8-byte stores of a row's two k-tiles use different
+// banks); a [k][x] operand keeps 32 k rows of 576 B as before.  One register set: the k-stage after the current one is
+// requested at the top of an iteration and split + stored behind its MFMAs.
+struct KcImage {                                   // [x][k] operand, one 32-deep stage
+    __bf16 hi0[256][16];
+    __bf16 pad0[32];
+    __bf16 hi1[256][16];
+    __bf16 pad1[32];
+    __bf16 lo0[256][16];
+    __bf16 pad2[32];
+    __bf16 lo1[256][16];
+    __bf16 pad3[32];
+};
+struct KxImage {                                   // [k][x] operand, one 32-deep stage
+    __bf16 thi[32][256 + 32];
+    __bf16 tlo[32][256 + 32];
+};
+union Image32 {
+    KcImage kc;
+    KxImage kx;
+};
+struct BigStage32 {
+    Image32 a[2];
+    Image32 b[2];
+};
+
+template <bool KC>
+struct BigLoader32 {
+    const float* p[4];
+    long long kstep;
+    __device__ inline void init(const float* __restrict__ P, long long ld, int x0, int k0, int tid) {
+        if (KC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = P + (long long)(x0 + (tid >> 3) + 64 * r) * ld + k0 + (tid & 7) * 4;
+            kstep = 32;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = P + (long long)(k0 + (tid >> 6) + 8 * r) * ld + x0 + (tid & 63) * 4;
+            kstep = 32 * ld;
+        }
+    }
+    __device__ inline void load(f32x4 (&v)[4], int ks) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const f32x4*>(p[r] + ks * kstep);
+    }
+};
+
+template <bool KC>
+__device__ inline void big_stage32(const f32x4 (&v)[4], Image32& S, int tid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+        if (KC) {
+            const int row = (tid >> 3) + 64 * r, kc = tid & 7, c4 = kc & 3;
+            const int col = (((c4 >> 1) ^ ((row >> 3) & 1)) << 3) + ((c4 & 1) << 2);
+            if (kc < 4) {
+                *reinterpret_cast<bf16x4*>(&S.kc.hi0[row][col]) = h;
+                *reinterpret_cast<bf16x4*>(&S.kc.lo0[row][col]) = l;
+            } else {
+                *reinterpret_cast<bf16x4*>(&S.kc.hi1[row][col]) = h;
+                *reinterpret_cast<bf16x4*>(&S.kc.lo1[row][col]) = l;
+            }
+        } else {
+            const int k = (tid >> 6) + 8 * r, x4 = (tid & 63) * 4;
+            *reinterpret_cast<bf16x4*>(&S.kx.thi[k][x4]) = h;
+            *reinterpret_cast<bf16x4*>(&S.kx.tlo[k][x4]) = l;
+        }
+    }
+}
+
+// MFMA operand fragment of k-tile t (0 / 1) of a 32-deep stage: rows x0 .. x0 + 31
+template <bool KC>
+__device__ inline void big_frag32(const Image32& S, int t, int x0, int lane, bf16x8& fh, bf16x8& fl) {
+    if constexpr (KC) {
+        const int row = x0 + (lane & 31), col = (((lane >> 5) ^ ((row >> 3) & 1)) << 3);
+        if (t == 0) {
+            fh = *reinterpret_cast<const bf16x8*>(&S.kc.hi0[row][col]);
+            fl = *reinterpret_cast<const bf16x8*>(&S.kc.lo0[row][col]);
+        } else {
+            fh = *reinterpret_cast<const bf16x8*>(&S.kc.hi1[row][col]);
+            fl = *reinterpret_cast<const bf16x8*>(&S.kc.lo1[row][col]);
+        }
+    } else {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int k0 = 16 * t + 8 * (g >> 1) + q, c0 = x0 + (g & 1) * 16 + 4 * pp;
+        const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.kx.thi[k0][c0]));
+        const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.kx.thi[k0 + 4][c0]));
+        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.kx.tlo[k0][c0]));
+        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&S.kx.tlo[k0 + 4][c0]));
+        fh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        fl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+template <bool AK, bool BK>
+__device__ inline void big_mma32(f32x16 (&acc)[4][2], const BigStage32& S, int buf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) big_frag32<BK>(S.b[buf], t, wn + j * 32, lane, bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 ah, al;
+            big_frag32<AK>(S.a[buf], t, wm + i * 32, lane, ah, al);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// nks 32-deep k-stages; same accumulation order per accumulator as the 16-deep pipelines (k-tile by k-tile)
+template <bool AK, bool BK>
+__device__ inline void big_pipeline32(f32x16 (&acc)[4][2], f32x4& csum, const bool want_csum, const BigLoader32<AK>& la,
+                                      const BigLoader32<BK>& lb, const int nks, BigStage32& S) {
+    const int tid = threadIdx.x;
+    if (nks <= 0) return;
+    f32x4 va[4], vb[4];
+    la.load(va, 0); lb.load(vb, 0);
+    big_stage32<AK>(va, S.a[0], tid);
+    big_stage32<BK>(vb, S.b[0], tid);
+    if (!AK && want_csum) csum += (va[0] + va[1]) + (va[2] + va[3]);
+    __syncthreads();
+    int ks = 0;
+    for (; ks + 1 < nks; ++ks) {
+        const int buf = ks & 1;
+        la.load(va, ks + 1); lb.load(vb, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);             // requests first: a whole stage of MFMAs hides them
+        big_mma32<AK, BK>(acc, S, buf);
+        big_stage32<AK>(va, S.a[buf ^ 1], tid);
+        big_stage32<BK>(vb, S.b[buf ^ 1], tid);
+        if (!AK && want_csum) csum += (va[0] + va[1]) + (va[2] + va[3]);
+        __syncthreads();
+    }
+    big_mma32<AK, BK>(acc, S, ks & 1);
+    __syncthreads();
+}
+
 __device__ inline void big_zero(f32x16 (&acc)[4][2]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -348,7 +348,7 @@ def test_eigh_sym_top_indefinite_matrix():
         assert np.abs(C @ V - V * w).max() <= 1e-10 * np.abs(wr).max()
 
 
-@pytest.mark.parametrize('n,k,kind', [(512, 10, 'mcca'), (1024, 30, 'mcca'), (600, 20, 'random'), (512, 12, 'clustered')])
+@pytest.mark.parametrize('n,k,kind', [(768, 10, 'mcca'), (1024, 30, 'mcca'), (800, 20, 'random'), (704, 12, 'clustered')])
 def test_eigh_sym_top_subspace_iteration(n, k, kind):
     """Large n, few pairs: the Chebyshev-filtered subspace iteration (not the full Jacobi) must give the pairs LAPACK gives --
     MCCA-like spectra (a few large generalised correlations over a bulk, negative tail), a random indefinite matrix (small

@@ -167,3 +167,31 @@ def test_weight_gradient_group_mixes_both_tile_shapes(tiles):
     again = run()
     for b, a in zip(big, again):
         assert torch.equal(b, a)                       # deterministic
+
+
+def test_opt_in_32_deep_stages_same_bits():
+    """XPS_GEMM_BIG_DEEP=1 (32-deep LDS stages with swizzled [x][k] images, read once per process): the direct forms must
+    still equal the 128-tile kernels bit for bit.  Own process because the switch is read at first use."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, ctypes as C\n"
+        "from cross_patient_speech_decoding_amd._lib import lib, call, rowmap\n"
+        "from cross_patient_speech_decoding_amd.nn_models import functional as xf\n"
+        "l = lib(); l.xps_set_gemm_precision(1)\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "M, N, K = 4096, 3072, 160\n"
+        "A = torch.randn(M, K, generator=g).cuda(); B = torch.randn(N, K, generator=g).cuda(); Bt = torch.randn(K, N, generator=g).cuda()\n"
+        "outs = []\n"
+        "for t in (0, 1):\n"
+        "    l.xps_set_gemm_big_tiles(t)\n"
+        "    c1 = torch.empty(M, N, device='cuda'); c2 = torch.empty(M, N, device='cuda')\n"
+        "    xf.gemm_nt(A, B, c1, M, N, K); xf.gemm_nn(A, Bt, c2, M, N, K)\n"
+        "    outs.append((c1, c2))\n"
+        "assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])\n"
+        "print('DEEP_OK')\n")
+    env = dict(os.environ, XPS_GEMM_BIG_DEEP='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert 'DEEP_OK' in r.stdout, r.stdout + r.stderr
