@@ -486,14 +486,23 @@ def main():
             # the capture runs one more training step: single process only (under DP it would issue collectives alone)
             out['roofline'] = time_dominant_kernel(model, c, capture_dominant_launch(step) if world == 1 else None)
             if world == 1 and not args.headline_only:
-                out['north_star_shard'] = north_star_shard(dev)
-                if precision != 'fp32':
-                    out['fp32'] = fp32_record(c, dev)
-                out['alignment'] = alignment_record(dev)
+                # sub-records never cost the headline line: a failure is reported in place of the record
+                for key, fn in (('north_star_shard', lambda: north_star_shard(dev)),
+                                ('fp32', (lambda: fp32_record(c, dev)) if precision != 'fp32' else None),
+                                ('alignment', lambda: alignment_record(dev))):
+                    if fn is None:
+                        continue
+                    try:
+                        out[key] = fn()
+                    except Exception as e:                                   # noqa: BLE001
+                        out[key] = {'error': f'{type(e).__name__}: {e}'[:300]}
         else:
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(c)
+            try:
+                out['cpu_baseline'] = cpu_baseline(c)
+            except Exception as e:                                           # noqa: BLE001
+                out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
