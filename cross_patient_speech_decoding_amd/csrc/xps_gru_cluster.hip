@@ -536,6 +536,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             int rn = r_pv + 2, sn = s_pv;
             if (rn >= NR) { rn -= NR; ++sn; }
             const unsigned char* src = dma_src(sn, rn);
+            // (half of them issued by the contraction waves between their MFMAs instead: 627 -> 635 us per launch; the round is
+            //  not paced by the slower role but by the spread of all eight waves at the barrier)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) dma_group(src, (it + 1) & 1, g4);
         }
@@ -641,7 +643,8 @@ struct ClBwd {
 };
 
 // Same two wave roles as the forward kernel.  Sub-iteration q = (ps, round r, gate segment g): contraction waves accumulate
-// segment g of round r (buffer q & 1), stream their quarter of sub-iteration q + 1's operand between the MFMA chunks and hand
+// segment g of round r (buffer q & 1), stream three quarters of their share of sub-iteration q + 1's operand between the MFMA
+// chunks (bf16x3 mode; the gate waves move the fourth quarter, first thing in every sub-iteration; fp32 mode: all of it) and hand
 // the finished products over after g == 2 (xacc, double buffered by round parity); gate waves act once per round, during its
 // first sub-iteration: gate math of the PREVIOUS round (products from xacc, inputs requested one round earlier), exchange rows,
 // outputs, then the requests for THIS round's inputs; wave 4 also keeps the flags.
@@ -681,12 +684,14 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     // sub-iteration (ps, r, g) reads the gate gradients that processing step ps - 1 wrote (parity (ps - 1) & 1); contraction
     // wave w moves pieces [16 w, 16 w + 16) in four groups of four
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+    // (w: the contraction wave whose quarter of the pieces is meant; gate wave 4 + w moves the last group of wave w's quarter)
+    const int dw = wave & 3;
     auto dma_src = [&](int ps_, int r_, int g_) -> const unsigned char* {
         const size_t chunk = (size_t)(((((ps_ - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r_) * 3 + g_);
-        return xb + chunk * Cf::CHUNK_BYTES + (size_t)(wave * 16) * 1024 + lane * 16;
+        return xb + chunk * Cf::CHUNK_BYTES + (size_t)(dw * 16) * 1024 + lane * 16;
     };
     auto dma_group = [&](const unsigned char* src, int buf, int grp) {
-        const int j = wave * 16 + grp * 4;
+        const int j = dw * 16 + grp * 4;
         const unsigned base = lds0 + (unsigned)(buf * TILE) + (unsigned)((j >> 1) * TS);
         const unsigned h = BF ? PS : 1024;
         cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
@@ -833,6 +838,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         }
         f32x4 acc[2];
         int ps = ps0, r = 0, g = 0;                      // (ps, r, g) of sub-iteration q
+#ifdef XPS_CL_STAMP
+        unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, s_bar = 0, s_work = 0, s_drain = 0;
+        CL_STAMP(sb2)
+#endif
         for (int q = q_begin; q < q_end; ++q) {
             int ps_n = ps, r_n = r, g_n = g + 1;         // sub-iteration q + 1
             if (g_n == 3) { g_n = 0; if (++r_n == NR) { r_n = 0; ++ps_n; } }
@@ -851,7 +860,11 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                     if constexpr (BF) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            if (has_next && (c & 3) == 0) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
+                            // (all four groups before the first chunk instead: 1120 -> 1197 us per launch)
+                            // three of this wave's four groups; gate wave 4 + wave moves the fourth (stamps: issuing 16 pieces cost a
+                            // contraction wave ~1300 cycles of a 3400-cycle sub-iteration while the gate waves idled at the barrier)
+                            // (two groups on gate waves 5-7 as well: 991 vs 992 us, no further gain)
+                            if (has_next && (c & 3) == 0 && tt * 2 + (c >> 2) < 3) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
                             const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
                             const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
@@ -882,9 +895,19 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                 *reinterpret_cast<f32x4*>(xw + 1024) = acc[1];
             }
             ps = ps_n; r = r_n; g = g_n;
+            CL_STAMP(sb3)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
+            CL_STAMP(sb0)
             __syncthreads();
+            CL_STAMP(sb1)
+            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb0)
+#ifdef XPS_CL_STAMP
+            sb2 = sb1;
+#endif
         }
+#ifdef XPS_CL_STAMP
+        if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; }
+#endif
         return;
     }
 
@@ -900,9 +923,23 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     };
     {
         int ps = ps0, r = 0, g = 0;
+#ifdef XPS_CL_STAMP
+        unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0;
+        CL_STAMP(sb2)
+#endif
         for (int q = q_begin; q < q_end; ++q) {
             // flag of the round that ended at q - 2: its exchange rows were stored during sub-iteration q - 1 and complete before
             // the last barrier
+            if constexpr (BF) {
+                // this wave's share of sub-iteration q + 1's operand: the fourth group of contraction wave (wave - 4)'s quarter,
+                // first in the stream so that the counted wait of g == 0 covers it
+                if (q + 1 < q_end) {
+                    int ps_n = ps, r_n = r, g_n = g + 1;
+                    if (g_n == 3) { g_n = 0; if (++r_n == NR) { r_n = 0; ++ps_n; } }
+                    dma_group(dma_src(ps_n, r_n, g_n), (q + 1) & 1, 3);
+                }
+                CL_FENCE();
+            }
             if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
                 int rp = r - 1, psp = ps;
                 if (rp < 0) { rp = NR - 1; --psp; }
@@ -921,13 +958,30 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                 CL_FENCE();
                 younger += epi_load(ps, r, ein);               // this round's inputs, used one round later
                 CL_FENCE();
+                CL_STAMP(sb3)
                 cl_wait_vmcnt(younger);                        // exchange rows complete; outputs / inputs stay in flight
+                CL_STAMP(sb4)
+                CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb4)
+#ifdef XPS_CL_STAMP
+                sb2 = sb4;
+#endif
             }
             if (g == 2) { pend_ps = ps; pend_r = r; }
+            CL_STAMP(sb3)
             if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+            if (BF && g != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
+            CL_STAMP(sb0)
             __syncthreads();
+            CL_STAMP(sb1)
+            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_poll, sb3, sb0) CL_ACC(s_work, sb2, sb3)
+#ifdef XPS_CL_STAMP
+            sb2 = sb1;
+#endif
             if (++g == 3) { g = 0; if (++r == NR) { r = 0; ++ps; } }
         }
+#ifdef XPS_CL_STAMP
+        if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; }
+#endif
     }
     if (pend_ps >= 0) finish(q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
 }

@@ -26,3 +26,18 @@ for save in (True, False):
     for role, ws_ in (('contraction', [0, 1, 2, 3]), ('gates', [4, 5, 6, 7])):
         sel = np.concatenate([raw[w::8] for w in ws_])
         print(f'   {role:12s} {np.median(sel[:, 0]) / rounds:8.0f} {np.median(sel[:, 1]) / rounds:8.0f} {np.median(sel[:, 2]) / rounds:8.0f}')
+
+# ---- backward (BPTT): per wave role, cycles per ROUND (3 sub-iterations): work / drain (vmcnt wait) / barrier wait / poll
+y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
+dy = (torch.randn(T, B, ndir * H) * 0.1).cuda()
+for _ in range(3):
+    xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 16384)()
+assert l.xps_debug_read_cluster_stamps(buf, 16384) == 0
+raw = np.array(buf[:], dtype=np.float64).reshape(2048, 8)
+rounds = (T - 1) * 8
+print('backward - cycles per round (median over workgroups): work / drain / barrier wait / poll')
+for role, ws_ in (('contraction', [0, 1, 2, 3]), ('gates 5-7', [5, 6, 7]), ('gate wave 4', [4])):
+    sel = np.concatenate([raw[w::8] for w in ws_])
+    print(f'   {role:12s} {np.median(sel[:, 0]) / rounds:8.0f} {np.median(sel[:, 1]) / rounds:8.0f} {np.median(sel[:, 2]) / rounds:8.0f} {np.median(sel[:, 3]) / rounds:8.0f}')
