@@ -429,12 +429,17 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
         if (want_csum) bf_colsum<AK, WM>(ra0, csum);
     }
     __syncthreads();
+#ifdef XPS_GSTAMP
+    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, s_ld = 0, s_mm = 0, s_st = 0, s_bar = 0;
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+        GSTAMP(g0)
         if (kt + 2 < nkt) {
             if (MODE) { la.template load_fast<MODE == 2>(ra0, kbeg + (kt + 2) * BKT); lb.template load_fast<MODE == 2>(rb0, kbeg + (kt + 2) * BKT); }
             else { la.load(ra0, A, ra, m0, M, kbeg + (kt + 2) * BKT, kend, tid, vecA); lb.load(rb0, B, rb, n0, N, kbeg + (kt + 2) * BKT, kend, tid, vecB); }
         }
+        GSTAMP(g1)
         {
             bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
@@ -450,6 +455,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+        GSTAMP(g2)
         if (kt + 1 < nkt) {
             bf_store<AK, WM>(ra1, S.a[buf ^ 1], tid);
             bf_store<BK, 128>(rb1, S.b[buf ^ 1], tid);
@@ -459,8 +465,19 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
 #pragma unroll
             for (int r = 0; r < LB::NV; ++r) rb1[r] = rb0[r];
         }
+        GSTAMP(g3)
         __syncthreads();
+#ifdef XPS_GSTAMP
+        GSTAMP(g4)
+        s_ld += g1 - g0; s_mm += g2 - g1; s_st += g3 - g2; s_bar += g4 - g3;
+#endif
     }
+#ifdef XPS_GSTAMP
+    if (lane == 0) {
+        const int wid = (((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave)) & 8191;
+        g_gstamp[wid * 4 + 0] = s_ld; g_gstamp[wid * 4 + 1] = s_mm; g_gstamp[wid * 4 + 2] = s_st; g_gstamp[wid * 4 + 3] = s_bar;
+    }
+#endif
 }
 
 template <bool AK, bool BK, int MI, bool EDGE = false>
