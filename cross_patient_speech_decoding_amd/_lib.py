@@ -72,6 +72,9 @@ SIGNATURES = {
     'xps_gru_seq_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'xps_gru_seq_bwd_f32_workspace': (_sz, [_i, _i, _i, _i]),
     'xps_gru_seq_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'xps_gru_seq_fused_dropout_supported': (_i, [_i, _i, _i, _i]),
+    'xps_gru_seq_fwd_drop_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, C.c_uint64, _vp, _sz, _vp]),
+    'xps_gru_seq_bwd_drop_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_uint64, _vp, _sz, _vp]),
     'xps_transpose_f32': (_i, [_vp, _vp, _i, _i, _vp]),
     'xps_transpose_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xps_bn_finalize_f32': (_i, [_vp, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp]),

@@ -49,5 +49,23 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 
 __device__ inline float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// counter-based RNG (splitmix64 finaliser over seed + element-pair index): two 24-bit uniforms per hash
+__device__ inline void rng_pair(unsigned long long seed, long long pair, float& u0, float& u1) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(pair + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    u0 = (float)((unsigned)(z >> 40)) * (1.0f / 16777216.0f);
+    u1 = (float)((unsigned)(z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+// keep decisions (1 / 0) of the four elements 4 q .. 4 q + 3 of a dropout site: THE definition every kernel uses
+// (xps_dropout_f32 and the GRU kernels that fuse the inter-layer dropout must agree bit for bit)
+__device__ inline f32x4 dropout_keep4(unsigned long long seed, long long q, float p) {
+    float u0, u1, u2, u3;
+    rng_pair(seed, 2 * q, u0, u1);
+    rng_pair(seed, 2 * q + 1, u2, u3);
+    return (f32x4){u0 >= p ? 1.f : 0.f, u1 >= p ? 1.f : 0.f, u2 >= p ? 1.f : 0.f, u3 >= p ? 1.f : 0.f};
+}
+
 // product precision of the matrix kernels (xps_set_gemm_precision): 0 = fp32 MFMA, 1 = bf16 split products
 int xps_internal_gemm_mode();

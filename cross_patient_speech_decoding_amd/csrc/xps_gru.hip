@@ -51,6 +51,10 @@ struct GruFwdParams {
     float* y_ext;
     float* saved;
     int T, B, H, ndir, Hp, ldh;
+    // fused inter-layer dropout (resident kernels only): y_drop (T x B x ndir*H) = y * keep * scale, keep = dropout_keep4(seed, index / 4)
+    float* y_drop;
+    float drop_p, drop_scale;
+    unsigned long long drop_seed;
 };
 
 template <bool VEC>
@@ -209,6 +213,10 @@ struct GruBwdParams {
     float* dghn;
     float* dh0;
     int T, B, H, ndir, Hp, ldg, ldc;
+    // dy is the gradient w.r.t. the DROPPED output of the forward kernel (resident kernels only): dy * keep * scale on the fly
+    int has_drop;
+    float drop_p, drop_scale;
+    unsigned long long drop_seed;
 };
 
 // Backward through time.  Per step: (1) lane-parallel gate gradients from the saved
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_fwd_resident_kernel(GruFwdPara
 #else
     constexpr int NCB = H / 32, LDB = H + 16;  // BF: 32-wide k chunks; bf16 row stride (conflict-free b128 reads)
 #endif
-    constexpr int NST = TPW * 5;               // 16-byte stores per lane and step: h, r, z, n, q per tile
+    constexpr int NST = TPW * 6;               // 16-byte stores per lane and step: h, r, z, n, q (, dropped h) per tile
     __shared__ __attribute__((aligned(16))) float hs[2][GBM][LDH];
     __shared__ __attribute__((aligned(16))) __bf16 hsb[BF ? 2 : 1][2][BF ? GBM : 1][BF ? LDB : 8];   // [buffer][hi, lo][trial][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -506,10 +514,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_fwd_resident_kernel(GruFwdPara
     float4 pend[NST];
     float* pend_y = nullptr;
     float* pend_sv = nullptr;
+    float* pend_yd = nullptr;
+    const bool do_drop = p.y_drop != nullptr;
     auto issue_store = [&](int k) {            // k is a compile-time constant at every call site
         const int tt = k % TPW, what = k / TPW;
         const int j = (wave + NW * tt) * 16 + 4 * kq;
         if (what == 0) *reinterpret_cast<float4*>(pend_y + j) = pend[k];
+        else if (what == 5) { if (do_drop) *reinterpret_cast<float4*>(pend_yd + j) = pend[k]; }
         else if (do_save) *reinterpret_cast<float4*>(pend_sv + (what - 1) * H + j) = pend[k];
     };
 
@@ -620,6 +631,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_fwd_resident_kernel(GruFwdPara
             pend[2 * TPW + tt] = make_float4(z_[0], z_[1], z_[2], z_[3]);
             pend[3 * TPW + tt] = make_float4(n_[0], n_[1], n_[2], n_[3]);
             pend[4 * TPW + tt] = make_float4(q_[0], q_[1], q_[2], q_[3]);
+            if (do_drop) {
+                // element index inside the (T, B, ndir * H) output = the index xps_dropout_f32 would see
+                const f32x4 m = dropout_keep4(p.drop_seed, (((long long)t * B + bc) * ldy + dir * H + j) >> 2, p.drop_p);
+                pend[5 * TPW + tt] = make_float4(o[0] * m[0] * p.drop_scale, o[1] * m[1] * p.drop_scale, o[2] * m[2] * p.drop_scale,
+                                                 o[3] * m[3] * p.drop_scale);
+            }
             *reinterpret_cast<float4*>(&hs[cur ^ 1][n][j]) = pend[tt];
             if constexpr (BF) {
                 bf16x4 sh, sl;
@@ -631,6 +648,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_fwd_resident_kernel(GruFwdPara
         }
         pend_y = p.y_ext + ((long long)(t + 1) * B + bc) * ldy + dir * H;
         pend_sv = do_save ? p.saved + (((long long)dir * T + t) * B + bc) * 4 * H : nullptr;
+        pend_yd = do_drop ? p.y_drop + ((long long)t * B + bc) * ldy + dir * H : nullptr;
         STAMP(st2)
         STAMP(st3)
         __syncthreads();
@@ -765,7 +783,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_bwd_resident_kernel(GruBwdPara
             float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, danr = dar, keep = dar, dan4 = dar;
             pend_live[e] = b < B;
             if (b < B) {
-                const float4 dy4 = in[e].dy;
+                float4 dy4 = in[e].dy;
+                if (p.has_drop) {              // dy arrives for the dropped output: the same decisions as the forward kernel's
+                    const f32x4 m = dropout_keep4(p.drop_seed, (((long long)t * B + b) * ldy + dir * H + j) >> 2, p.drop_p);
+                    dy4 = make_float4(dy4.x * m[0] * p.drop_scale, dy4.y * m[1] * p.drop_scale, dy4.z * m[2] * p.drop_scale,
+                                      dy4.w * m[3] * p.drop_scale);
+                }
                 const float4 cy4 = *reinterpret_cast<const float4*>(&Cy[r][j]);
                 const float4 rg = in[e].rg, zg = in[e].zg, ng = in[e].ng, q = in[e].q, hp = in[e].hp;
                 float o_dar[4], o_daz[4], o_dan[4], o_danr[4], o_keep[4];
@@ -1207,9 +1230,39 @@ extern "C" long long xps_gru_seq_status_offset(int T, int B, int H, int ndir) {
     return cluster_shape_ok(T, B, H, ndir) ? (long long)xps_internal_gru_cluster_status_offset(B, H, ndir) : -1;
 }
 
+// the shapes whose forward / backward run the register-resident kernels (the only ones that fuse the inter-layer dropout)
+extern "C" int xps_gru_seq_fused_dropout_supported(int T, int B, int H, int ndir) {
+    if (T < 1 || B < 1 || (ndir != 1 && ndir != 2)) return 0;
+    if (cluster_shape_ok(T, B, H, ndir)) return 0;
+    return (H == 128 || H == 64) ? 1 : 0;
+}
+
+static int gru_seq_fwd_impl(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                            const float* h0, float* y_ext, float* saved,
+                            int T, int B, int H, int ndir, float* y_drop, float drop_p, unsigned long long drop_seed,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                    const float* h0, float* y_ext, float* saved,
                                    int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream) {
+    return gru_seq_fwd_impl(gi, w_hh, b_hh, h0, y_ext, saved, T, B, H, ndir, nullptr, 0.f, 0ull, workspace, workspace_bytes, stream);
+}
+
+extern "C" int xps_gru_seq_fwd_drop_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                        const float* h0, float* y_ext, float* saved,
+                                        int T, int B, int H, int ndir, float* y_drop, float drop_p, uint64_t drop_seed,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(y_drop && drop_p >= 0.f && drop_p < 1.f, "y_drop must be given, 0 <= p < 1");
+    XPS_CHECK_ARG(xps_gru_seq_fused_dropout_supported(T, B, H, ndir) && aligned16(y_drop),
+                  "fused dropout: shape not on the resident kernels (see xps_gru_seq_fused_dropout_supported)");
+    return gru_seq_fwd_impl(gi, w_hh, b_hh, h0, y_ext, saved, T, B, H, ndir, y_drop, drop_p, (unsigned long long)drop_seed, workspace,
+                            workspace_bytes, stream);
+}
+
+static int gru_seq_fwd_impl(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                            const float* h0, float* y_ext, float* saved,
+                            int T, int B, int H, int ndir, float* y_drop, float drop_p, unsigned long long drop_seed,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     XPS_CHECK_ARG(gi && w_hh && b_hh && y_ext, "null argument");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
@@ -1224,6 +1277,7 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     GruFwdParams p;
     p.gi = gi; p.h0 = h0; p.y_ext = y_ext; p.saved = saved;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;
+    p.y_drop = y_drop; p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
     p.Hp = ((H + 15) / 16) * 16;
     p.ldh = p.Hp + 4;
     bool vec = (H % 4 == 0);
@@ -1235,6 +1289,7 @@ extern "C" int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, co
     }
     const size_t lds_bytes = (size_t)2 * GBM * p.ldh * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident state tile");
+    XPS_CHECK_ARG(!y_drop || vec, "fused dropout needs 16-byte aligned weights");
     if (H > 128 && use_step_path()) {
         // large hidden size: one fused GEMM + gate launch per time step (see gru_step_fwd_kernel)
         hipStream_t st = (hipStream_t)stream;
@@ -1284,9 +1339,32 @@ extern "C" size_t xps_gru_seq_bwd_f32_workspace(int T, int B, int H, int ndir) {
     return (size_t)2 * ndir * B * H * sizeof(float) + 16;       // ping-pong running gradient of the per-step path
 }
 
+static int gru_seq_bwd_impl(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                            const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                            int T, int B, int H, int ndir, int has_drop, float drop_p, unsigned long long drop_seed,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                    const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                                    int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream) {
+    return gru_seq_bwd_impl(dy, dhn, y_ext, saved, w_hh, w_hh_t, dgi, dghn, dh0, T, B, H, ndir, 0, 0.f, 0ull, workspace, workspace_bytes, stream);
+}
+
+extern "C" int xps_gru_seq_bwd_drop_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                                        const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                                        int T, int B, int H, int ndir, float drop_p, uint64_t drop_seed,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(dy && drop_p >= 0.f && drop_p < 1.f, "dy must be given, 0 <= p < 1");
+    XPS_CHECK_ARG(xps_gru_seq_fused_dropout_supported(T, B, H, ndir),
+                  "fused dropout: shape not on the resident kernels (see xps_gru_seq_fused_dropout_supported)");
+    return gru_seq_bwd_impl(dy, dhn, y_ext, saved, w_hh, w_hh_t, dgi, dghn, dh0, T, B, H, ndir, 1, drop_p, (unsigned long long)drop_seed,
+                            workspace, workspace_bytes, stream);
+}
+
+static int gru_seq_bwd_impl(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                            const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                            int T, int B, int H, int ndir, int has_drop, float drop_p, unsigned long long drop_seed,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     XPS_CHECK_ARG(y_ext && saved && w_hh && w_hh_t && dgi && dghn, "null argument");
     XPS_CHECK_ARG(dy || dhn, "at least one of dy / dhn must be given");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
@@ -1302,6 +1380,7 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
     GruBwdParams p;
     p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;
+    p.has_drop = has_drop; p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
     p.Hp = ((H + 15) / 16) * 16;
     p.ldg = 3 * p.Hp + 4;
     p.ldc = p.Hp + 4;
@@ -1313,6 +1392,7 @@ extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const floa
     }
     const size_t lds_bytes = (size_t)GBM * (p.ldg + p.ldc) * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident gradient tile");
+    XPS_CHECK_ARG(!has_drop || vec, "fused dropout needs 16-byte aligned weights");
     if (H > 128 && use_step_path()) {
         if (!workspace || workspace_bytes < xps_gru_seq_bwd_f32_workspace(T, B, H, ndir) || !aligned16(workspace)) {
             xps_set_error("xps_gru_seq_bwd_f32: workspace too small or misaligned");

@@ -296,16 +296,7 @@ __global__ void mask_scale_kernel(const float* __restrict__ x, const float* __re
         out[i] = x[i] * mask[i] * scale;
 }
 
-// counter-based RNG (splitmix64 finaliser over seed + element-pair index): two 24-bit uniforms per hash
-__device__ inline void rng_pair(unsigned long long seed, long long pair, float& u0, float& u1) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(pair + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    u0 = (float)((unsigned)(z >> 40)) * (1.0f / 16777216.0f);
-    u1 = (float)((unsigned)(z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
-}
-
+// (rng_pair / dropout_keep4: xps_common.h, shared with the GRU kernels that fuse the inter-layer dropout)
 // mask[i] = (u_i >= p); optionally out[i] = x[i] * mask[i] * scale in the same pass.  mask may be NULL: the backward
 // pass regenerates the decisions from (seed, index) with the same call on the incoming gradient instead of
 // reading a stored mask.  VEC: 16-byte accesses, two RNG pairs per thread (n % 4 == 0, 16-byte aligned buffers).
@@ -315,10 +306,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     if (VEC) {
         const long long nquad = n / 4;
         for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (long long)gridDim.x * blockDim.x) {
-            float u0, u1, u2, u3;
-            rng_pair(seed, 2 * q, u0, u1);
-            rng_pair(seed, 2 * q + 1, u2, u3);
-            const f32x4 m = {u0 >= p ? 1.f : 0.f, u1 >= p ? 1.f : 0.f, u2 >= p ? 1.f : 0.f, u3 >= p ? 1.f : 0.f};
+            const f32x4 m = dropout_keep4(seed, q, p);
             if (mask) *reinterpret_cast<f32x4*>(mask + 4 * q) = m;
             if (x) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * q);

@@ -323,19 +323,39 @@ def set_gru_cluster_mode(name):
     call('xps_set_gru_cluster_mode', modes[name])
 
 
-def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save):
+_fused_drop_ok = {}
+
+
+def fused_dropout_supported(T, B, H, ndir):
+    """The recurrence kernels of this shape apply the inter-layer dropout themselves (XPS_FUSED_DROPOUT=0: never)."""
+    key = (T, B, H, ndir)
+    v = _fused_drop_ok.get(key)
+    if v is None:
+        v = os.environ.get('XPS_FUSED_DROPOUT', '1') != '0' and bool(lib().xps_gru_seq_fused_dropout_supported(T, B, H, ndir))
+        if len(_fused_drop_ok) < 256:
+            _fused_drop_ok[key] = v
+    return v
+
+
+def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     dev = gi.device
     y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
     saved = torch.empty(ndir, T, B, 4 * H, dtype=_f32, device=dev) if save else None
     nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
+    if drop is not None:
+        # inter-layer dropout fused into the recurrence kernel: a second output y_drop = y * keep / (1 - p)
+        y_drop = torch.empty(T, B, ndir * H, dtype=_f32, device=dev)
+        call('xps_gru_seq_fwd_drop_f32', _ptr(gi), _ptr_array(w_hh), _ptr_array(b_hh), _ptr(h0), _ptr(y_ext),
+             _ptr(saved), T, B, H, ndir, _ptr(y_drop), float(drop[0]), int(drop[1]), _ptr(ws), nbytes, _stream())
+        return y_ext, saved, y_drop
     call('xps_gru_seq_fwd_f32', _ptr(gi), _ptr_array(w_hh), _ptr_array(b_hh), _ptr(h0), _ptr(y_ext),
          _ptr(saved), T, B, H, ndir, _ptr(ws), nbytes, _stream())
     _note_gru_status(ws, T, B, H, ndir)
     return y_ext, saved
 
 
-def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
+def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=None):
     """BPTT kernel.  dy (T,B,ndir*H) or None, dhn (ndir,B,H) or None.  Returns dgi (ndir,T,B,3H),
     dghn (ndir,T,B,H), dh0 (ndir,B,H) or None."""
     dev = y_ext.device
@@ -355,6 +375,11 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0):
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
     nbytes = _gru_ws_bytes('xps_gru_seq_bwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
+    if drop is not None and dy is not None:
+        # dy is the gradient w.r.t. the dropped output of the forward kernel: the decisions are re-made while it is loaded
+        call('xps_gru_seq_bwd_drop_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
+             _ptr(dghn), _ptr(dh0), T, B, H, ndir, float(drop[0]), int(drop[1]), _ptr(ws), nbytes, _stream())
+        return dgi, dghn, dh0
     call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
          _ptr(dghn), _ptr(dh0), T, B, H, ndir, _ptr(ws), nbytes, _stream())
     _note_gru_status(ws, T, B, H, ndir)
@@ -424,7 +449,7 @@ class GRURecurFn(torch.autograd.Function):
 HN_NONE, HN_STACK, HN_SUM = 0, 1, 2
 
 
-class GRULayerFn(torch.autograd.Function):
+class GRULayerDropFn(torch.autograd.Function):
     """One (bi)directional GRU layer over a time-major input x (T, B, In):
     input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel + ONE grouped
     launch for all six weight/bias gradients.  weights: per direction (w_ih, w_hh, b_ih, b_hh).
@@ -433,7 +458,9 @@ class GRULayerFn(torch.autograd.Function):
     the backward gets ONE (B, H) gradient for both directions); HN_NONE: None (inner layers)."""
 
     @staticmethod
-    def forward(ctx, x, ndir, hn_mode, *wb):
+    def forward(ctx, x, ndir, hn_mode, drop_p, *wb):
+        """drop_p > 0: the layer's output goes through inverted dropout (torch.nn.GRU's inter-layer dropout), fused into the
+        recurrence kernels where they support it (fused_dropout_supported), else a separate pass; hn stays undropped."""
         ctx.set_materialize_grads(False)
         _need_gpu(x, *wb)
         x = x.contiguous()
@@ -448,7 +475,16 @@ class GRULayerFn(torch.autograd.Function):
         call('xps_gemm_nt_multi_f32', _ptr(x), C.byref(ra), _ptr_array(w_ih), C.byref(rb), _ptr_array([gi[d] for d in range(ndir)]),
              C.byref(rc), _ptr_array(b_ih), ndir, T * B, 3 * H, In, _stream())
         save = any(ctx.needs_input_grad)
-        y_ext, saved = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
+        drop = None
+        y_drop = None
+        if drop_p and drop_p > 0.0:
+            drop = (float(drop_p), next_dropout_seed())
+        ctx.drop = drop
+        ctx.drop_fused = bool(drop is not None and fused_dropout_supported(T, B, H, ndir))
+        if ctx.drop_fused:
+            y_ext, saved, y_drop = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save, drop)
+        else:
+            y_ext, saved = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
         if save:
             ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
         ctx.params = wb
@@ -457,6 +493,12 @@ class GRULayerFn(torch.autograd.Function):
         # (forward: t = T-1, reverse: t = 0), returned separately so that a consumer of the final state
         # only (the seq2seq encoder) sends back a small gradient instead of a zero-padded (T, B, .) one
         y = y_ext[1:T + 1]
+        if y_drop is not None:
+            y = y_drop
+        elif drop is not None:                  # shapes without the fused path: the same decisions in a separate pass
+            out = torch.empty(T, B, ndir * H, dtype=_f32, device=x.device)
+            call('xps_dropout_f32', _ptr(y), _ptr(out), None, out.numel(), drop[0], drop[1], _stream())
+            y = out
         if hn_mode == HN_NONE:
             hn = None
         elif hn_mode == HN_SUM:
@@ -473,7 +515,12 @@ class GRULayerFn(torch.autograd.Function):
         x, y_ext, saved, *w = ctx.saved_tensors
         w_ih, w_hh = w[:ndir], w[ndir:]
         wb = ctx.params
-        dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False)
+        if ctx.drop is not None and dy is not None and not ctx.drop_fused:
+            dyc = dy.contiguous()
+            dyd = torch.empty_like(dyc)
+            call('xps_dropout_f32', _ptr(dyc), _ptr(dyd), None, dyc.numel(), ctx.drop[0], ctx.drop[1], _stream())
+            dy = dyd
+        dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False, ctx.drop if ctx.drop_fused else None)
         dev = x.device
         # weight gradients first: on the side stream they depend on the recurrence kernel only, so they start
         # together with the input-gradient GEMM below instead of after it (and are out of the way earlier)
@@ -503,7 +550,20 @@ class GRULayerFn(torch.autograd.Function):
         grads = []
         for d in range(ndir):
             grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, *grads)
+
+
+class GRULayerFn(torch.autograd.Function):
+    """GRULayerDropFn without the inter-layer dropout: (x, ndir, hn_mode, *weights)."""
+
+    @staticmethod
+    def forward(ctx, x, ndir, hn_mode, *wb):
+        return GRULayerDropFn.forward(ctx, x, ndir, hn_mode, 0.0, *wb)
+
+    @staticmethod
+    def backward(ctx, dy, dhn):
+        g = GRULayerDropFn.backward(ctx, dy, dhn)
+        return g[:3] + g[4:]
 
 
 # --------------------------------------------------------------------------- #

@@ -147,9 +147,10 @@ class EncoderRNN(nn.Module):
         L = rnn.num_layers
         y = x
         for l in range(L):
-            y, last = XF.GRULayerFn.apply(y, 2, XF.HN_SUM if l == L - 1 else XF.HN_NONE, *_gru_layer_weights(rnn, l, 2))
-            if l < L - 1:
-                y = XF.dropout(y, rnn.dropout, self.training)
+            # inter-layer dropout (all layers but the last, training only) travels with the layer: its recurrence kernels
+            # write the dropped output and re-make the decisions in the backward pass (no separate passes over y / dy)
+            p_drop = float(rnn.dropout) if (l < L - 1 and self.training) else 0.0
+            y, last = XF.GRULayerDropFn.apply(y, 2, XF.HN_SUM if l == L - 1 else XF.HN_NONE, p_drop, *_gru_layer_weights(rnn, l, 2))
         return y, last                                    # last = h_fwd(T-1) + h_bwd(0)
 
     def forward(self, x):

@@ -163,6 +163,20 @@ size_t xps_gru_seq_bwd_f32_workspace(int T, int B, int H, int ndir);
 int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                         const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                         int T, int B, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
+/* Inter-layer dropout of a multi-layer GRU (torch.nn.GRU(dropout=p): nn_models/models.py:661-663, applied to the outputs of
+ * every layer but the last) fused into the recurrence kernels of the register-resident shapes (H = 64 / 128;
+ * xps_gru_seq_fused_dropout_supported says which): the forward kernel also writes y_drop (T x B x ndir*H) = y * keep / (1 - p)
+ * with keep = the decisions xps_dropout_f32(seed) makes for the same flat index, the backward kernel takes dy as the gradient
+ * w.r.t. y_drop and applies the same decisions while it loads it.  Same bits as the separate xps_dropout_f32 passes. */
+int xps_gru_seq_fused_dropout_supported(int T, int B, int H, int ndir);
+int xps_gru_seq_fwd_drop_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                             const float* h0, float* y_ext, float* saved,
+                             int T, int B, int H, int ndir, float* y_drop, float drop_p, uint64_t drop_seed,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int xps_gru_seq_bwd_drop_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                             const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                             int T, int B, int H, int ndir, float drop_p, uint64_t drop_seed,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
 /* 1..4 equally shaped matrices in one launch (host arrays of device pointers): both directions' W_hh^T */

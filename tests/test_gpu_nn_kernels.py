@@ -386,3 +386,46 @@ def test_cross_entropy_and_adamw_vs_torch():
         xf.adamw_step(p, gd, m, v, ss, 0.5, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step)
         np.testing.assert_allclose(gd.cpu().numpy(), p_ref.grad.numpy(), rtol=2e-6, atol=1e-9)   # clipped in place
         np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('H,ndir', [(128, 2), (64, 1), (96, 2)])
+def test_inter_layer_dropout_fused_into_the_gru_kernels_same_bits(H, ndir, gemm_precision, monkeypatch):
+    """torch.nn.GRU's inter-layer dropout (nn_models/models.py:661-663): the recurrence kernels of the resident shapes write
+    the dropped output and re-make the decisions while they load dy.  Same seed -> the same bits as the separate
+    xps_dropout_f32 passes (forward output, input gradient, every weight gradient); H = 96 has no fused path (both runs take
+    the separate passes: the switch must be harmless there)."""
+    xf = XF()
+    T, B, In = 7, 50, 24
+    torch.manual_seed(H + ndir)
+    gru = torch.nn.GRU(In, H, 1, bidirectional=(ndir == 2))
+    ws = []
+    for d in range(ndir):
+        sfx = '_l0' + ('_reverse' if d else '')
+        ws += [getattr(gru, n + sfx).detach().clone().cuda() for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, B, In, generator=g).cuda()
+    wt = torch.randn(T, B, ndir * H, generator=g).cuda()
+    monkeypatch.setattr(xf, 'next_dropout_seed', lambda: 0x1234567)
+
+    def run(fused):
+        monkeypatch.setattr(xf, 'fused_dropout_supported', (lambda *a: bool(lib().xps_gru_seq_fused_dropout_supported(*a))) if fused else (lambda *a: False))
+        xg = x.clone().requires_grad_(True)
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        y, hn = xf.GRULayerDropFn.apply(xg, ndir, xf.HN_STACK, 0.3, *wl)
+        ((y * wt).sum() + hn.sum()).backward()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), hn.detach().clone(), xg.grad.clone()] + [w.grad.clone() for w in wl]
+
+    from cross_patient_speech_decoding_amd._lib import lib
+    assert bool(lib().xps_gru_seq_fused_dropout_supported(T, B, H, ndir)) == (H in (64, 128))
+    sep = run(False)
+    fus = run(True)
+    for a, b in zip(sep, fus):
+        assert torch.equal(a, b)
+    y = sep[0]
+    zero = float((y == 0).float().mean())
+    assert 0.25 < zero < 0.35                                   # ~30 % of the outputs dropped
+    y0, hn0 = xf.GRULayerFn.apply(x, ndir, xf.HN_STACK, *ws)    # no dropout: kept elements are y / 0.7, hn is undropped
+    keep = y != 0
+    np.testing.assert_allclose(y[keep].cpu().numpy(), (y0[keep] / 0.7).cpu().numpy(), rtol=1e-6)
+    assert torch.equal(hn0, sep[1])
