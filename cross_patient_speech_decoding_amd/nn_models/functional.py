@@ -570,20 +570,27 @@ class GRULayerFn(torch.autograd.Function):
 # TemporalConv: Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                      #
 # --------------------------------------------------------------------------- #
 POST_SYNCBN_HOOKS = []
+# World size from which the data-parallel code paths (SyncBN exchanges, gradient all-reduce) run.  2 in production;
+# XPS_DP_SINGLE_RANK_COLLECTIVES=1 makes it 1, so that a ONE-rank RCCL communicator executes every collective of the path on a
+# one-GPU box (tests/test_gpu_training.py: ReduceOp.AVG, the async tail all-reduce issued from the autograd thread, device_id
+# init) -- averaging over one rank must reproduce the plain step.
+MIN_DP_WORLD = 1 if os.environ.get('XPS_DP_SINGLE_RANK_COLLECTIVES') == '1' else 2
 
 
 def _group_world(group):
+    """> 1 when the data-parallel paths are to run for this group (see MIN_DP_WORLD)."""
     import torch.distributed as dist
     if group is not None and dist.is_available() and dist.is_initialized():
-        return dist.get_world_size(group)
+        w = dist.get_world_size(group)
+        return 2 if (w == 1 and MIN_DP_WORLD == 1) else w
     return 1
 
 
 def _dist_sum_(t, group):
     import torch.distributed as dist
-    if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_DP_WORLD:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return dist.get_world_size(group)
+        return max(dist.get_world_size(group), 2) if MIN_DP_WORLD == 1 else dist.get_world_size(group)
     return 1
 
 

@@ -75,10 +75,12 @@ class FlatAdamW:
         self._early = None
         self._comm_stream = None
         world, _ = _world(group)
+        # the data-parallel paths run from world size XF.MIN_DP_WORLD on (2; 1 only in the single-rank RCCL rehearsal test)
+        self._dp = group is not None and dist.is_available() and dist.is_initialized() and world >= XF.MIN_DP_WORLD
         # RCCL averages in the collective (no extra pass over the buffer); gloo (CPU tests) sums, then one scale
-        self._avg = world > 1 and dist.get_backend(group) == 'nccl'
+        self._avg = self._dp and dist.get_backend(group) == 'nccl'
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        if (world > 1 and os.environ.get('XPS_DP_OVERLAP', '1') != '0' and XF.DIRECT_GRAD
+        if (self._dp and os.environ.get('XPS_DP_OVERLAP', '1') != '0' and XF.DIRECT_GRAD
                 and hasattr(module, 'temporal_conv')):
             first = {id(p) for p in module.temporal_conv.parameters()}
             idx = [i for i, p in enumerate(self.params) if id(p) not in first]
@@ -133,7 +135,7 @@ class FlatAdamW:
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 p.grad = view
-        if world > 1:
+        if self._dp or world > 1:
             if self._early is not None:                    # the tail went out during backward: only the head is left
                 self._early.wait()                         # (current stream waits for the collective)
                 self._early = None

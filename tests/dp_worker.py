@@ -123,6 +123,34 @@ def main():
     a = ap.parse_args()
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
+    if a.device == 'nccl1':
+        # ONE rank on a real RCCL communicator (XPS_DP_SINGLE_RANK_COLLECTIVES=1 makes the data-parallel paths run at world
+        # size 1): ReduceOp.AVG, device_id= init, SyncBN exchanges and the async tail all-reduce issued from the autograd
+        # thread all execute on RCCL; averaging over one rank must give the plain step bit for bit
+        assert os.environ.get('XPS_DP_SINGLE_RANK_COLLECTIVES') == '1'
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        X, y = data()
+        from cross_patient_speech_decoding_amd.nn_models import functional as XF
+        assert XF.MIN_DP_WORLD == 1
+        calls = []
+        real = dist.all_reduce
+        def spy(t, *args, **kw):
+            calls.append((tuple(t.shape), kw.get('op', args[0] if args else None), bool(kw.get('async_op', False))))
+            return real(t, *args, **kw)
+        dist.all_reduce = spy
+        r_dp = hip_step(0, 1, X, y, dist.group.WORLD)
+        dist.all_reduce = real
+        r_1 = hip_step(0, 1, X, y, None)
+        for u, v in zip(r_dp, r_1):
+            assert (np.asarray(u) == np.asarray(v)).all(), 'one-rank RCCL step differs from the plain step'
+        ops = [c[1] for c in calls]
+        assert any(c[2] for c in calls), f'no async all-reduce was issued: {calls}'
+        assert dist.ReduceOp.AVG in ops and dist.ReduceOp.SUM in ops, ops
+        dist.barrier()
+        dist.destroy_process_group()
+        print('DP_OK', len(calls), 'collectives on RCCL')
+        return
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=worker, args=(r, a.world, a.device, q)) for r in range(a.world)]

@@ -128,6 +128,19 @@ def test_data_parallel_two_ranks_equal_single_process():
     assert 'DP_OK' in out.stdout
 
 
+def test_rccl_collectives_execute_on_a_one_rank_communicator():
+    """A one-GPU box cannot hold two RCCL ranks, but it can hold ONE: with XPS_DP_SINGLE_RANK_COLLECTIVES=1 the data-parallel
+    paths run at world size 1, so `init_process_group('nccl', device_id=)`, the SyncBN exchanges, `ReduceOp.AVG` on the flat
+    gradient and the async tail all-reduce issued from the autograd thread all EXECUTE on RCCL (tests/dp_worker.py --device nccl1
+    checks that they were issued and that the step equals the plain step bit for bit).  The 2-rank test below needs 2 GPUs."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29549', XPS_DP_SINGLE_RANK_COLLECTIVES='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', '1', '--device', 'nccl1'], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+
+
 def test_data_parallel_two_ranks_rccl_one_device_each():
     """The production configuration: backend 'nccl' (= RCCL), one process per GPU, device bound at init_process_group,
     ReduceOp.AVG, the tail of the flat gradient all-reduced asynchronously from the autograd thread.  Needs two GPUs: the
