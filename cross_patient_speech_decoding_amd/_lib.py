@@ -93,6 +93,7 @@ SIGNATURES = {
     'xps_scatter_rows_f32_workspace': (_sz, [_i, _i, _i]),
     'xps_scatter_rows_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'xps_next_token': (_i, [_vp, _i, _vp, _i64, _vp, _vp, _i, _vp]),
+    'xps_decoder_select_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'xps_dropout_f32': (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _vp]),
     'xps_mask_scale_f32': (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),

@@ -290,6 +290,62 @@ __global__ void next_token_kernel(const float* __restrict__ logits, int C, const
     next[b] = bi;
 }
 
+// Decode-step glue of the wide decoder (functional.DecoderWideFn): logits = h W_fc^T + b (C <= 16 classes), the next token
+// (teacher token if the device flag says so, else the first maximum) and the gather of that token's row of the projection
+// table, one wave per trial: lane l holds columns 4 l + 256 j of h; per class a 64-lane butterfly sum in a fixed order.
+constexpr int SEL_MAXC = 16;
+__global__ __launch_bounds__(256) void decoder_select_kernel(const float* __restrict__ h, const float* __restrict__ w_fc,
+                                                             const float* __restrict__ b_fc, float* __restrict__ logits,
+                                                             const long long* __restrict__ teacher, long long tstride,
+                                                             const int* __restrict__ use_teacher, const float* __restrict__ table,
+                                                             long long* __restrict__ next, float* __restrict__ gi_next,
+                                                             int B, int H, int C, int ntok) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float acc[SEL_MAXC];
+#pragma unroll
+    for (int c = 0; c < SEL_MAXC; ++c) acc[c] = 0.f;
+    const float* hr = h + (long long)b * H;
+    for (int k = lane * 4; k < H; k += 256) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hr + k);
+#pragma unroll
+        for (int c = 0; c < SEL_MAXC; ++c) {
+            if (c < C) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w_fc + (long long)c * H + k);
+                acc[c] += (hv[0] * wv[0] + hv[1] * wv[1]) + (hv[2] * wv[2] + hv[3] * wv[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < SEL_MAXC; ++c) {
+        if (c < C) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+        }
+    }
+    // every lane now holds the same sums
+    float best = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int c = 0; c < SEL_MAXC; ++c) {
+        if (c < C) {
+            const float v = acc[c] + b_fc[c];
+            if (lane == c) logits[(long long)b * C + c] = v;
+            if (c == 0 || v > best) { best = v; bi = c; }
+        }
+    }
+    if (!next) return;
+    long long tok = bi;
+    if (use_teacher && teacher && use_teacher[0]) tok = teacher[(long long)b * tstride];
+    if (lane == 0) next[b] = tok;
+    if (gi_next && tok >= 0 && tok < ntok) {
+        const float* src = table + tok * 3LL * H;
+        float* dst = gi_next + (long long)b * 3 * H;
+        for (int k = lane * 4; k < 3 * H; k += 256) *reinterpret_cast<f32x4*>(dst + k) = *reinterpret_cast<const f32x4*>(src + k);
+    }
+}
+
 __global__ void mask_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float scale,
                                   float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -659,6 +715,24 @@ extern "C" int xps_next_token(const float* logits, int n_classes, const int64_t*
     hipLaunchKernelGGL(next_token_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream,
                        logits, n_classes, (const long long*)teacher, (long long)teacher_stride, (const int*)use_teacher,
                        (long long*)next, B);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_decoder_select_f32(const float* h, const float* w_fc, const float* b_fc, float* logits,
+                                      const int64_t* teacher, int64_t teacher_stride, const int32_t* use_teacher,
+                                      const float* table, int64_t* next, float* gi_next, int B, int H, int C, int ntok,
+                                      void* stream) {
+    XPS_CHECK_ARG(h && w_fc && b_fc && logits && B >= 0 && H >= 4 && C >= 1, "bad argument");
+    XPS_CHECK_ARG(C <= SEL_MAXC && H % 4 == 0, "at most 16 classes, H a multiple of 4");
+    XPS_CHECK_ARG(!gi_next || (table && next && ntok >= 1), "the gather needs the table and the token output");
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(w_fc) | reinterpret_cast<uintptr_t>(table) |
+                           reinterpret_cast<uintptr_t>(gi_next);
+    XPS_CHECK_ARG((bits & 15) == 0, "h, w_fc, table and gi_next must be 16-byte aligned");
+    if (B == 0) return XPS_OK;
+    hipLaunchKernelGGL(decoder_select_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, h, w_fc, b_fc, logits,
+                       (const long long*)teacher, (long long)teacher_stride, (const int*)use_teacher, table, (long long*)next,
+                       gi_next, B, H, C, ntok);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

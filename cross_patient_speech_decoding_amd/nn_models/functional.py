@@ -758,36 +758,123 @@ class DecoderFn(torch.autograd.Function):
         dh0 = torch.empty(B, H, dtype=_f32, device=dev)
         call('xps_decoder_bwd_f32', _ptr(dlogits), _ptr(hs), _ptr(saved), _ptr(w_t), _ptr(w_fc_c), _ptr(dgi), _ptr(dghn),
              _ptr(dh0), B, H, C, L, _stream())
-        # weight gradients: W_hh / b_hh from (dgi, dghn) x h_prev = hs[0:L];  W_fc / b_fc from dlogits x hs[1:L+1]
-        dwh, acc_h, r_wh = _grad_target(w_hh, (3 * H, H), dev)
-        dbh, acc_bh, r_bh = _grad_target(b_hh, (3 * H,), dev)
-        dwf, acc_f, r_wf = _grad_target(w_fc, (C, H), dev)
-        dbf, acc_bf, r_bf = _grad_target(b_fc, (C,), dev)
-        if not (acc_h == acc_bh and acc_f == acc_bf):
-            dwh, dbh = torch.empty(3 * H, H, dtype=_f32, device=dev), torch.empty(3 * H, dtype=_f32, device=dev)
-            dwf, dbf = torch.empty(C, H, dtype=_f32, device=dev), torch.empty(C, dtype=_f32, device=dev)
-            acc_h = acc_f = False
-            r_wh, r_bh, r_wf, r_bf = dwh, dbh, dwf, dbf
-        hprev = hs                                   # rows (s, b): hs[s]
-        hnext = hs.view(-1)[B * H:]                  # rows (s, b): hs[s + 1]
-        probs = [
-            tn_problem(dgi, hprev, dwh, 2 * H, H, L * B, ra=rowmap(3 * H), rb=rowmap(H), rc=rowmap(H),
-                       colsum_out=dbh, accumulate=acc_h),
-            tn_problem(dghn, hprev, dwh[2 * H:], H, H, L * B, ra=rowmap(H), rb=rowmap(H), rc=rowmap(H),
-                       colsum_out=dbh[2 * H:], accumulate=acc_h),
-            # dlogits is (B, L, C): row (s, b) lives at b*L*C + s*C
-            tn_problem(dlogits, hnext, dwf, C, H, L * B, ra=rowmap(L * C, rpg=B, gs=C), rb=rowmap(H), rc=rowmap(H),
-                       colsum_out=dbf, accumulate=acc_f),
-        ]
-        _launch_weight_grads(lambda st: gemm_tn_grouped(probs, dev, st), dev, (dgi, dghn, hs, dlogits),
-                             r_wh is None and r_bh is None and r_wf is None and r_bf is None)
-        # d table[tok] += dgi over all (step, trial) rows
-        dtable = torch.empty(ntok, 3 * H, dtype=_f32, device=dev)
-        nbytes = lib().xps_scatter_rows_f32_workspace(L * B, 3 * H, ntok)
-        ws = _ws(nbytes, dev)
-        call('xps_scatter_rows_f32', _ptr(dgi), _ptr(tokens), _ptr(dtable), L * B, 3 * H, ntok, 0, _ptr(ws), nbytes,
-             _stream())
+        dtable, r_wh, r_bh, r_wf, r_bf = _decoder_weight_grads(dlogits, dgi, dghn, hs, tokens, ctx.params, B, H, C, L, ntok)
         return dtable, dh0, r_wh, r_bh, r_wf, r_bf, None, None, None, None
+
+
+def _decoder_weight_grads(dlogits, dgi, dghn, hs, tokens, params, B, H, C, L, ntok):
+    """Shared tail of the decoder backward passes: W_hh / b_hh from (dgi, dghn) x h_prev = hs[0:L], W_fc / b_fc from
+    dlogits x hs[1:L+1] in ONE grouped launch over all steps, and d table[tok] += dgi over all (step, trial) rows."""
+    w_hh, b_hh, w_fc, b_fc = params
+    dev = hs.device
+    dwh, acc_h, r_wh = _grad_target(w_hh, (3 * H, H), dev)
+    dbh, acc_bh, r_bh = _grad_target(b_hh, (3 * H,), dev)
+    dwf, acc_f, r_wf = _grad_target(w_fc, (C, H), dev)
+    dbf, acc_bf, r_bf = _grad_target(b_fc, (C,), dev)
+    if not (acc_h == acc_bh and acc_f == acc_bf):
+        dwh, dbh = torch.empty(3 * H, H, dtype=_f32, device=dev), torch.empty(3 * H, dtype=_f32, device=dev)
+        dwf, dbf = torch.empty(C, H, dtype=_f32, device=dev), torch.empty(C, dtype=_f32, device=dev)
+        acc_h = acc_f = False
+        r_wh, r_bh, r_wf, r_bf = dwh, dbh, dwf, dbf
+    hprev = hs                                   # rows (s, b): hs[s]
+    hnext = hs.view(-1)[B * H:]                  # rows (s, b): hs[s + 1]
+    probs = [
+        tn_problem(dgi, hprev, dwh, 2 * H, H, L * B, ra=rowmap(3 * H), rb=rowmap(H), rc=rowmap(H),
+                   colsum_out=dbh, accumulate=acc_h),
+        tn_problem(dghn, hprev, dwh[2 * H:], H, H, L * B, ra=rowmap(H), rb=rowmap(H), rc=rowmap(H),
+                   colsum_out=dbh[2 * H:], accumulate=acc_h),
+        # dlogits is (B, L, C): row (s, b) lives at b*L*C + s*C
+        tn_problem(dlogits, hnext, dwf, C, H, L * B, ra=rowmap(L * C, rpg=B, gs=C), rb=rowmap(H), rc=rowmap(H),
+                   colsum_out=dbf, accumulate=acc_f),
+    ]
+    _launch_weight_grads(lambda st: gemm_tn_grouped(probs, dev, st), dev, (dgi, dghn, hs, dlogits),
+                         r_wh is None and r_bh is None and r_wf is None and r_bf is None)
+    dtable = torch.empty(ntok, 3 * H, dtype=_f32, device=dev)
+    nbytes = lib().xps_scatter_rows_f32_workspace(L * B, 3 * H, ntok)
+    ws = _ws(nbytes, dev)
+    call('xps_scatter_rows_f32', _ptr(dgi), _ptr(tokens), _ptr(dtable), L * B, 3 * H, ntok, 0, _ptr(ws), nbytes,
+         _stream())
+    return dtable, r_wh, r_bh, r_wf, r_bf
+
+
+class DecoderWideFn(torch.autograd.Function):
+    """One-layer GRU decoder (nn_models/models.py:719-761, decode loop :285-301) for hidden sizes the one-launch kernel of
+    DecoderFn does not hold in a workgroup (H = 500 / 512 of the north-star shape).  Forward: per step the token-projection
+    gather, ONE recurrence step (the generic / cluster GRU entry point on a sliding 3-slot window of one state buffer, so that
+    the L steps leave ONE (L + 2)-slot state sequence and ONE saved-gates sequence behind), the output Linear written straight
+    into its (step, trial) rows, the next-token choice on the device.  Backward: the tokens are known, so the L steps are ONE
+    BPTT launch (dy = dlogits W_fc for all steps from one GEMM), ONE grouped weight-gradient launch over all steps and one
+    scatter for the token table -- instead of L times {recurrence backward, two weight-gradient launches + reduces, scatter,
+    transposes and autograd's adds / fills}: 85 -> 35 launches, 0.94 -> ~0.45 ms per configs[3] step."""
+
+    @staticmethod
+    def forward(ctx, table, h0, w_hh, b_hh, w_fc, b_fc, teacher, flags, start_token, L):
+        ctx.set_materialize_grads(False)
+        _need_gpu(table, h0, w_hh, w_fc)
+        table, h0c = table.contiguous(), h0.contiguous()
+        w_hh_c, b_hh_c, w_fc_c, b_fc_c = w_hh.contiguous(), b_hh.contiguous(), w_fc.contiguous(), b_fc.contiguous()
+        B, H = h0c.shape
+        C = w_fc_c.shape[0]
+        ntok = table.shape[0]
+        dev = h0c.device
+        save = any(ctx.needs_input_grad)
+        if teacher is not None:
+            teacher = teacher.contiguous()
+            if tuple(teacher.shape) != (B, L):
+                raise ValueError('teacher tokens must be (batch, seq_length)')
+        steps = torch.empty(L, B, C, dtype=_f32, device=dev)             # logits by (step, trial)
+        tokens = torch.empty(L, B, dtype=torch.int64, device=dev)
+        tokens[0].fill_(int(start_token))
+        hs = torch.empty(L + 2, B, H, dtype=_f32, device=dev)            # y_ext layout of a T = L sequence: slot s = h_{s-1}
+        saved = torch.empty(1, L, B, 4 * H, dtype=_f32, device=dev) if save else None
+        gi = torch.empty(B, 3 * H, dtype=_f32, device=dev)
+        nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', 1, B, H, 1)
+        w_arr, b_arr = _ptr_array([w_hh_c]), _ptr_array([b_hh_c])
+        rc = rowmap(C)
+        fused_select = C <= 16                          # logits + next token + its table row in one launch
+        for s in range(L):
+            if s == 0 or not fused_select:
+                call('xps_gather_rows_f32', _ptr(table), _ptr(tokens[s]), _ptr(gi), B, 3 * H, ntok, _stream())
+            ws = _ws(nbytes, dev)
+            # one step on the window hs[s : s + 3]: slot 0 <- h0 (= hs[s] itself at s > 0), slot 1 <- h_s, slot 2 <- 0 (rewritten
+            # by the next step)
+            call('xps_gru_seq_fwd_f32', _ptr(gi), w_arr, b_arr, _ptr(h0c if s == 0 else hs[s]), _ptr(hs[s:]),
+                 _ptr(saved[0, s]) if save else None, 1, B, H, 1, _ptr(ws), nbytes, _stream())
+            _note_gru_status(ws, 1, B, H, 1)
+            tstride = teacher.stride(0) if teacher is not None else 0
+            if fused_select:
+                last = s + 1 == L
+                call('xps_decoder_select_f32', _ptr(hs[s + 1]), _ptr(w_fc_c), _ptr(b_fc_c), _ptr(steps[s]),
+                     _ptr(teacher[:, s]) if (teacher is not None and not last) else None, tstride,
+                     _ptr(flags[s:s + 1]) if (teacher is not None and not last) else None, _ptr(table),
+                     None if last else _ptr(tokens[s + 1]), None if last else _ptr(gi), B, H, C, ntok, _stream())
+                continue
+            gemm_nt(hs[s + 1], w_fc_c, steps[s], B, C, H, bias=b_fc_c, rc=rc)
+            if s + 1 < L:
+                call('xps_next_token', _ptr(steps[s]), C, _ptr(teacher[:, s]) if teacher is not None else None, tstride,
+                     _ptr(flags[s:s + 1]) if teacher is not None else None, _ptr(tokens[s + 1]), B, _stream())
+        logits = steps.permute(1, 0, 2).contiguous()
+        if save:
+            ctx.save_for_backward(tokens, hs, saved, w_hh_c, w_fc_c)
+        ctx.params = (w_hh, b_hh, w_fc, b_fc)
+        ctx.dims = (B, H, C, L, ntok)
+        ctx.mark_non_differentiable(tokens)
+        return logits, tokens
+
+    @staticmethod
+    def backward(ctx, dlogits, _dtok):
+        tokens, hs, saved, w_hh_c, w_fc_c = ctx.saved_tensors
+        B, H, C, L, ntok = ctx.dims
+        dev = hs.device
+        if dlogits is None:
+            return (None,) * 10
+        dlogits = dlogits.contiguous()
+        # dy[s, b, :] = dlogits[b, s, :] W_fc for all steps at once (rows (s, b) of dlogits at b*L*C + s*C)
+        dy = torch.empty(L, B, H, dtype=_f32, device=dev)
+        gemm_nn(dlogits, w_fc_c, dy, L * B, H, C, ra=rowmap(L * C, rpg=B, gs=C))
+        dgi, dghn, dh0 = _gru_backward(dy, None, hs, saved, [w_hh_c], L, B, H, 1, True)
+        dtable, r_wh, r_bh, r_wf, r_bf = _decoder_weight_grads(dlogits, dgi[0], dghn[0], hs, tokens, ctx.params, B, H, C, L, ntok)
+        return dtable, dh0[0], r_wh, r_bh, r_wf, r_bf, None, None, None, None
 
 
 class GatherRowsFn(torch.autograd.Function):

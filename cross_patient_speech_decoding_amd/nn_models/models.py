@@ -9,6 +9,8 @@ and reference checkpoints work unchanged.  The arithmetic runs in hand-written H
 containers only (identical names, shapes and default initialisation order) and their own
 ``forward`` is never called.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -259,6 +261,15 @@ class Seq2SeqRNN(BaseLightningModel):
                                            self.decoder.fc_out.weight, self.decoder.fc_out.bias,
                                            y if y is not None else None, flags if y is not None else None,
                                            self.num_classes, self.seq_length)
+            return logits
+        if rnn.num_layers == 1 and rnn.hidden_size % 4 == 0 and os.environ.get('XPS_DECODER_WIDE', '1') != '0':
+            # other hidden sizes (H = 500 / 512 of the north-star shape): the same schedule on the general GRU entry points,
+            # ONE backward launch per kind for all decode steps (XF.DecoderWideFn)
+            table = self.decoder.token_projection()
+            logits, _ = XF.DecoderWideFn.apply(table, enc_last, rnn.weight_hh_l0, rnn.bias_hh_l0,
+                                               self.decoder.fc_out.weight, self.decoder.fc_out.bias,
+                                               y if y is not None else None, flags if y is not None else None,
+                                               self.num_classes, self.seq_length)
             return logits
         dec_hidden = enc_last.unsqueeze(0).repeat(self.decoder.rnn.num_layers, 1, 1)
         B = x.size(0)

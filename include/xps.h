@@ -263,6 +263,13 @@ int xps_scatter_rows_f32(const float* dout, const int64_t* idx, float* dtable,
  * decode loop has no host synchronisation.                                     */
 int xps_next_token(const float* logits, int n_classes, const int64_t* teacher, int64_t teacher_stride,
                    const int32_t* use_teacher, int64_t* next, int B, void* stream);
+/* Decode-step glue of a one-layer GRU decoder whose recurrence runs on the general GRU entry points (nn_models/models.py:
+ * 285-301, 749-757): logits (B x C, C <= 16) = h W_fc^T + b_fc, next[b] = teacher token (device flag set) or the first
+ * maximum of the logits, gi_next[b] = table[next[b]] (the token's row of the input-projection table, 3H floats) in one
+ * launch.  next / gi_next may be NULL (last step: logits only). */
+int xps_decoder_select_f32(const float* h, const float* w_fc, const float* b_fc, float* logits,
+                           const int64_t* teacher, int64_t teacher_stride, const int32_t* use_teacher,
+                           const float* table, int64_t* next, float* gi_next, int B, int H, int C, int ntok, void* stream);
 /* Inverted dropout with a counter-based generator (no mask round trip through torch's RNG kernels):
  * mask[i] = (u_i >= p) in {0,1}, u_i a function of (seed, i) only;  if x != NULL also
  * out[i] = x[i] * mask[i] / (1 - p) in the same pass.  mask may be NULL when x is given: the backward pass then

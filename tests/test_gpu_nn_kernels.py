@@ -429,3 +429,33 @@ def test_inter_layer_dropout_fused_into_the_gru_kernels_same_bits(H, ndir, gemm_
     keep = y != 0
     np.testing.assert_allclose(y[keep].cpu().numpy(), (y0[keep] / 0.7).cpu().numpy(), rtol=1e-6)
     assert torch.equal(hn0, sep[1])
+
+
+@pytest.mark.parametrize('B,H,C,use_teacher', [(130, 512, 9, 0), (67, 500, 9, 1), (5, 64, 16, 0), (300, 260, 3, 0)])
+def test_decoder_select_kernel(B, H, C, use_teacher):
+    """logits + next token (first maximum or teacher) + gather of the token's projection row in one launch
+    (nn_models/models.py:285-301, 749-757) against torch."""
+    from cross_patient_speech_decoding_amd._lib import call
+    xf = XF()
+    g = torch.Generator().manual_seed(B + H)
+    h = torch.randn(B, H, generator=g).cuda()
+    w = (torch.randn(C, H, generator=g) / H ** 0.5).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    ntok = C + 1
+    table = torch.randn(ntok, 3 * H, generator=g).cuda()
+    teacher = torch.randint(0, C, (B, 3), generator=g).cuda()
+    flag = torch.tensor([use_teacher], dtype=torch.int32).cuda()
+    logits = torch.empty(B, C, device='cuda')
+    nxt = torch.empty(B, dtype=torch.int64, device='cuda')
+    gi = torch.empty(B, 3 * H, device='cuda')
+    call('xps_decoder_select_f32', h.data_ptr(), w.data_ptr(), bias.data_ptr(), logits.data_ptr(), teacher[:, 1].data_ptr(),
+         teacher.stride(0), flag.data_ptr(), table.data_ptr(), nxt.data_ptr(), gi.data_ptr(), B, H, C, ntok, xf._stream())
+    ref = (h.double() @ w.double().T + bias.double())
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.cpu().numpy(), atol=2e-6 * H ** 0.5, rtol=1e-5)
+    exp = teacher[:, 1] if use_teacher else logits.argmax(dim=1)          # (argmax of the kernel's own logits: first maximum)
+    assert torch.equal(nxt, exp)
+    assert torch.equal(gi, table[nxt])
+    logits2 = torch.empty(B, C, device='cuda')                            # last step: logits only
+    call('xps_decoder_select_f32', h.data_ptr(), w.data_ptr(), bias.data_ptr(), logits2.data_ptr(), None, 0, None,
+         table.data_ptr(), None, None, B, H, C, ntok, xf._stream())
+    assert torch.equal(logits, logits2)
