@@ -362,6 +362,71 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
     }
 }
 
+// The same reduction with ONE thread per 16-byte vector summing every split in index order (eight loads in flight): for groups
+// with few splits (the 256-tile launches of configs[3]: 3-10 slabs) the four split lanes + LDS fold of the kernel above leave
+// one or two loads in flight per thread (92 us for 147 MB); XPS_TN_REDUCE=lanes|flat overrides the choice (flat: <= 10 splits).
+__global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_flat(TnGroup g, const float* __restrict__ ws) {
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool live = idx < g.total_out;
+    int pi = 0;
+    long long base = 0;
+    if (live) {
+#pragma unroll 1
+        for (int i = 0; i < g.n; ++i) {
+            const long long sz = tn_split_stride((long long)((g.p[i].M + BM - 1) / BM) * g.p[i].tiles_n, g.p[i].M, g.p[i].colsum != nullptr);
+            if (idx < base + sz) { pi = i; break; }
+            base += sz;
+        }
+    }
+    const TnProb& P = g.p[pi];
+    const long long tile_floats = (long long)((P.M + BM - 1) / BM) * P.tiles_n * TN_TILE;
+    const long long split_stride = tn_split_stride(tile_floats / TN_TILE, P.M, P.colsum != nullptr);
+    const long long e = idx - base;                       // [0, tile_floats): products in slab order, then M column sums
+    if (live) {
+        // every split in index order by ONE thread, eight 16-byte loads in flight (few splits: no lanes to fold, no LDS)
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        const float* src = ws + P.slab_off + e;
+        int z = 0;
+        for (; z + 8 <= P.splits; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long long)(z + u) * split_stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s4 += v[u];
+        }
+        {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = z + u < P.splits ? *reinterpret_cast<const f32x4*>(src + (long long)(z + u) * split_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s4 += v[u];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float* dst = nullptr;
+            bool is_cs = false;
+            if (e < tile_floats) {
+                const int tile = (int)(e / TN_TILE);
+                int r, cc;
+                slab_decode((int)(e % TN_TILE) + c, r, cc);
+                const int row = (tile / P.tiles_n) * BM + r, col = (tile % P.tiles_n) * BN + cc;
+                if (row < P.M && col < P.N)                                        // else: padding of an edge tile
+                    dst = P.C + (P.rc.rpg >= P.M ? (long long)row * P.rc.ld : P.rc.off(row)) + col;
+            } else {
+                is_cs = true;
+                if (e - tile_floats + c < P.M) dst = P.colsum + (e - tile_floats + c);   // else: alignment padding
+            }
+            if (dst) {
+                float s = s4[c];
+                // accumulate bit 0: products AND column sums add to their destinations; bit 1: the column sums only
+                if ((P.accumulate & 1) || ((P.accumulate & 2) && is_cs)) s += *dst;
+                *dst = s;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 256 x 256 tiles on 8 waves (xps_gemm_big.h): large interior shapes in bf16 split-product mode.
 // ---------------------------------------------------------------------------------------------------------------
@@ -897,7 +962,14 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     else
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, false>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     XPS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT * 4)), dim3(256), 0, (hipStream_t)stream, g,
+    int max_splits = 1;
+    for (int i = 0; i < n; ++i) max_splits = g.p[i].splits > max_splits ? g.p[i].splits : max_splits;
+    static const int red_mode = [] { const char* e = getenv("XPS_TN_REDUCE"); return !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'l' ? 2 : 0)); }();
+    if (red_mode == 1 || (red_mode == 0 && max_splits <= 10))
+        hipLaunchKernelGGL(gemm_tn_grouped_reduce_flat, dim3(cdiv(g.total_out, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g,
+                           (const float*)workspace);
+    else
+        hipLaunchKernelGGL(gemm_tn_grouped_reduce, dim3(cdiv(g.total_out, RED_OUT * 4)), dim3(256), 0, (hipStream_t)stream, g,
                        (const float*)workspace);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
