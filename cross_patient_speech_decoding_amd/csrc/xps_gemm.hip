@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce(TnGroup g, const f
 
 // The same reduction with ONE thread per 16-byte vector summing every split in index order (eight loads in flight): for groups
 // with few splits (the 256-tile launches of configs[3]: 3-10 slabs) the four split lanes + LDS fold of the kernel above leave
-// one or two loads in flight per thread (92 us for 147 MB); XPS_TN_REDUCE=lanes|flat overrides the choice (flat: <= 10 splits).
+// one or two loads in flight per thread (92 us for 147 MB); XPS_TN_REDUCE=lanes|flat overrides the choice (flat: <= 32 splits;
+// measured on the whole step with XPS_TN_BLOCKS = 768 / 512 / 384 / 256 x lanes / flat: 512 + flat wins on both workloads).
 __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_flat(TnGroup g, const float* __restrict__ ws) {
     const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     const bool live = idx < g.total_out;
@@ -803,7 +804,7 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
     static const int target_blocks = [] {
         const char* e = getenv("XPS_TN_BLOCKS");
         int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 768;
+        return v > 0 ? v : 512;              // (768 until the flat reduce existed: 512 + flat is -5 % on the cfg-2 step, -1.7 % on configs[3])
     }();
     // problems the 256 x 256 kernel takes (whole tiles, plain aligned operands, a long k range); the others stay on
     // the 128 x 128 kernel.  Each class shares its own block budget among its problems in proportion to their tiles.
@@ -965,7 +966,7 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     int max_splits = 1;
     for (int i = 0; i < n; ++i) max_splits = g.p[i].splits > max_splits ? g.p[i].splits : max_splits;
     static const int red_mode = [] { const char* e = getenv("XPS_TN_REDUCE"); return !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'l' ? 2 : 0)); }();
-    if (red_mode == 1 || (red_mode == 0 && max_splits <= 10))
+    if (red_mode == 1 || (red_mode == 0 && max_splits <= 32))
         hipLaunchKernelGGL(gemm_tn_grouped_reduce_flat, dim3(cdiv(g.total_out, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g,
                            (const float*)workspace);
     else
