@@ -13,19 +13,20 @@ _lib = None
 
 class RowMap(C.Structure):
     """xps_rowmap: row i lives at (i // rpg) * gs + (i % rpg) * ld."""
-    _fields_ = [('gs', C.c_int64), ('ld', C.c_int64), ('rpg', C.c_int32), ('pad_', C.c_int32)]
+    _fields_ = [('gs', C.c_int64), ('ld', C.c_int64), ('rpg', C.c_int32), ('fmt', C.c_int32)]
 
 
 _rowmaps = {}
 
 
-def rowmap(ld, rpg=1 << 30, gs=0):
+def rowmap(ld, rpg=1 << 30, gs=0, fmt=0):
     """xps_rowmap descriptor.  Instances are cached and shared (the library only reads them; embedding one in an
-    xps_tn_problem copies it): building a ctypes struct costs ~2 us and a training step needs ~40 of them."""
-    key = (ld, rpg, gs)
+    xps_tn_problem copies it): building a ctypes struct costs ~2 us and a training step needs ~40 of them.
+    fmt = 1 (XPS_FMT_SPLIT4): the GEMM input operand holds pre-split bf16 hi / lo groups (include/xps.h)."""
+    key = (ld, rpg, gs, fmt)
     r = _rowmaps.get(key)
     if r is None:
-        r = RowMap(int(gs), int(ld), int(rpg), 0)
+        r = RowMap(int(gs), int(ld), int(rpg), int(fmt))
         if len(_rowmaps) < 4096:
             _rowmaps[key] = r
     return r
@@ -75,6 +76,8 @@ SIGNATURES = {
     'xps_gru_seq_fused_dropout_supported': (_i, [_i, _i, _i, _i]),
     'xps_gru_seq_fwd_drop_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, C.c_uint64, _vp, _sz, _vp]),
     'xps_gru_seq_bwd_drop_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_uint64, _vp, _sz, _vp]),
+    'xps_gru_seq_bwd_split4_supported': (_i, [_i, _i, _i, _i]),
+    'xps_gru_seq_bwd_split4_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_uint64, _vp, _sz, _vp]),
     'xps_transpose_f32': (_i, [_vp, _vp, _i, _i, _vp]),
     'xps_transpose_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'xps_bn_finalize_f32': (_i, [_vp, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp]),
@@ -95,6 +98,7 @@ SIGNATURES = {
     'xps_next_token': (_i, [_vp, _i, _vp, _i64, _vp, _vp, _i, _vp]),
     'xps_decoder_select_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'xps_dropout_f32': (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _vp]),
+    'xps_split4_f32': (_i, [_vp, _vp, _i64, _f, C.c_uint64, _vp]),
     'xps_mask_scale_f32': (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'xps_cross_entropy_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),

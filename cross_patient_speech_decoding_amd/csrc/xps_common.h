@@ -32,6 +32,7 @@ void xps_set_error(const char* fmt, ...);
 struct RowMap {
     long long gs, ld;
     int rpg;
+    int fmt = 0;      // XPS_FMT_F32 / XPS_FMT_SPLIT4 (xps.h): element format of the operand the map addresses
     __host__ __device__ inline long long off(int i) const {
         return (long long)(i / rpg) * gs + (long long)(i % rpg) * ld;
     }
@@ -42,6 +43,7 @@ static inline RowMap to_rowmap(const xps_rowmap* r) {
     m.gs = r->gs;
     m.ld = r->ld;
     m.rpg = r->rpg < 1 ? 1 : r->rpg;
+    m.fmt = r->fmt;
     return m;
 }
 
@@ -60,6 +62,19 @@ __device__ inline void rng_pair(unsigned long long seed, long long pair, float& 
 }
 // keep decisions (1 / 0) of the four elements 4 q .. 4 q + 3 of a dropout site: THE definition every kernel uses
 // (xps_dropout_f32 and the GRU kernels that fuse the inter-layer dropout must agree bit for bit)
+// XPS_FMT_SPLIT4 (xps.h): the four fp32 values of an aligned group as bf16 hi[0..3] | lo[0..3] in the same 16 bytes,
+// hi = bf16(x), lo = bf16(x - hi): the split the bf16x3 tile kernels make while staging (xps_gemm_tile.h: bf_split).
+__device__ inline f32x4 split4_pack(const f32x4 v) {
+    typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+    bf16x8_ o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        o[j] = h;
+        o[4 + j] = (__bf16)(v[j] - (float)h);
+    }
+    return __builtin_bit_cast(f32x4, o);
+}
 __device__ inline f32x4 dropout_keep4(unsigned long long seed, long long q, float p) {
     float u0, u1, u2, u3;
     rng_pair(seed, 2 * q, u0, u1);

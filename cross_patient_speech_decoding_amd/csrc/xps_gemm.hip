@@ -435,46 +435,52 @@ extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
 
 // C (+)= A B (+ A2 B2) + bias, plain leading dimensions.  1-D grid, logical order (m-tile, n-tile).
 // DEEP: 32-deep LDS stages (k ranges multiples of 32), see xps_gemm_big.h
-template <bool AK, bool BK, bool DEEP>
+// FMT >= 0 (16-deep stages): the operand formats are compile-time (bit 0: A, bit 1: B are XPS_FMT_SPLIT4) -- ONE k loop in the
+// kernel; FMT < 0: the run-time flags select among four loops (kernels that have the registers for it)
+template <bool AK, bool BK, bool DEEP, int FMT = -1>
 __device__ inline void big_accumulate(f32x16 (&acc)[4][2], f32x4& csum, bool want_csum, const float* __restrict__ A, long long lda,
-                                      const float* __restrict__ B, long long ldb, int m0, int n0, int kbeg, int kend) {
+                                      const float* __restrict__ B, long long ldb, int m0, int n0, int kbeg, int kend,
+                                      const bool preA = false, const bool preB = false) {
     if constexpr (DEEP) {
         xps_big::BigStage32& st = *reinterpret_cast<xps_big::BigStage32*>(big_smem);
         xps_big::BigLoader32<AK> la;
         xps_big::BigLoader32<BK> lb;
         la.init(A, lda, m0, kbeg, threadIdx.x);
         lb.init(B, ldb, n0, kbeg, threadIdx.x);
-        xps_big::big_pipeline32<AK, BK>(acc, csum, want_csum, la, lb, (kend - kbeg) / 32, st);
+        xps_big::big_pipeline32<AK, BK>(acc, csum, want_csum, la, lb, (kend - kbeg) / 32, st, preA, preB);
     } else {
         xps_big::BigStage& st = *reinterpret_cast<xps_big::BigStage*>(big_smem);
         xps_big::BigLoader<AK> la;
         xps_big::BigLoader<BK> lb;
         la.init(A, lda, m0, kbeg, threadIdx.x);
         lb.init(B, ldb, n0, kbeg, threadIdx.x);
-        xps_big::big_pipeline<AK, BK>(acc, csum, want_csum, la, lb, (kend - kbeg) / BKT, st);
+        if constexpr (FMT >= 0) xps_big::big_pipeline_t<AK, BK, (FMT & 1) != 0, (FMT & 2) != 0>(acc, csum, want_csum, la, lb, (kend - kbeg) / BKT, st);
+        else xps_big::big_pipeline<AK, BK>(acc, csum, want_csum, la, lb, (kend - kbeg) / BKT, st, preA, preB);
     }
 }
 
-template <bool AK, bool BK, bool DEEP>
+template <bool AK, bool BK, bool DEEP, int FMT = 0>
 __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                            long long ldb, const float* __restrict__ A2, const float* __restrict__ B2,
                                                            int K2, float* __restrict__ C, long long ldc,
-                                                           const float* __restrict__ bias, int N, int K, int accumulate) {
+                                                           const float* __restrict__ bias, int N, int K, int accumulate, int fmt) {
     const int tiles_n = N / xps_big::TN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * xps_big::TM, n0 = (lid % tiles_n) * xps_big::TN;
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
-    big_accumulate<AK, BK, DEEP>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K);
-    if (A2) big_accumulate<AK, BK, DEEP>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2);
+    // fmt: bit 0 = A (and A2), bit 1 = B (and B2) are XPS_FMT_SPLIT4 operands; 16-deep stages: fmt == FMT (template), two
+    // k loops in the kernel instead of eight (which spilled 300-400 registers)
+    big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K, (fmt & 1) != 0, (fmt & 2) != 0);
+    if (A2) big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2, (fmt & 1) != 0, (fmt & 2) != 0);
     xps_big::big_store_c(acc, C, ldc, bias, m0, n0, accumulate);
 }
 
 // same A, up to 4 (B, bias, C): logical order (m-tile, problem, n-tile)
 template <bool DEEP>
 __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* __restrict__ A, long long lda, NtMulti pm, long long ldb,
-                                                                    long long ldc, int N, int K, int nprob) {
+                                                                    long long ldc, int N, int K, int nprob, int fmt) {
     const int tiles_n = N / xps_big::TN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int per_m = nprob * tiles_n, rem = lid % per_m;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* 
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
-    big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K);
+    big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K, (fmt & 1) != 0, (fmt & 2) != 0);
     xps_big::big_store_c(acc, pm.C[z], ldc, pm.bias[z], m0, n0, 0);
 }
 
@@ -509,7 +515,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big_tn_kernel(TnGroup g, float* _
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    big_accumulate<false, false, DEEP>(acc, csum, want_cs, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, kend);
+    big_accumulate<false, false, DEEP>(acc, csum, want_cs, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, kend,
+                                       (P.vecA & 2) != 0, (P.vecB & 2) != 0);
     float* sub[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -550,6 +557,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool map_vec_ok(const float* p, const RowMap& r) {
     return aligned16(p) && (r.ld % 4 == 0) && (r.gs % 4 == 0);
+}
+// XPS_FMT_SPLIT4 input operand (xps.h): 2 = to be OR-ed into the kernel's vec flag, 0 = plain fp32, -1 = not servable
+// (needs whole, aligned 16-byte groups along the contiguous index: `extent` = its length; bf16x3 mode is checked by the caller)
+inline int split4_flag(const float* p, const RowMap& r, long long extent) {
+    if (r.fmt == 0) return 0;
+    if (r.fmt != 1 || !map_vec_ok(p, r) || extent % 4 != 0) return -1;
+    return 2;
 }
 
 int tn_splits(int M, int N, int K) {
@@ -619,8 +633,15 @@ template <bool AK, bool BK>
 int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& rb, const float* A2, const float* B2, int K2,
                 float* C, const RowMap& rc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st) {
     const int kchunk = ((K + BKT - 1) / BKT) * BKT + BKT;
-    const int vecA = (int)(map_vec_ok(A, ra) && (!A2 || map_vec_ok(A2, ra)));
-    const int vecB = (int)(map_vec_ok(B, rb) && (!B2 || map_vec_ok(B2, rb)));
+    int vecA = (int)(map_vec_ok(A, ra) && (!A2 || map_vec_ok(A2, ra)));
+    int vecB = (int)(map_vec_ok(B, rb) && (!B2 || map_vec_ok(B2, rb)));
+    // XPS_FMT_SPLIT4 operands: bit 1 of the vec flags (-2: the request cannot be served)
+    int fA = split4_flag(A, ra, AK ? K : M), fB = split4_flag(B, rb, BK ? K : N);
+    if (A2 && fA > 0) fA = split4_flag(A2, ra, AK ? K2 : M);
+    if (B2 && fB > 0) fB = split4_flag(B2, rb, BK ? K2 : N);
+    if (fA < 0 || fB < 0 || ((fA | fB) && (!bf_mode() || M <= SM_MAXM))) return -2;
+    vecA |= fA; vecB |= fB;
+    const int fmt = (fA ? 1 : 0) | (fB ? 2 : 0);
     if (M <= SM_MAXM) {
         hipLaunchKernelGGL((gemm_small_kernel<AK, BK>), dim3(cdiv(N, 64)), dim3(1024), 0, st, A, ra, B, rb, A2, B2, K2, C, rc,
                            bias, M, N, K, accumulate, vecB);
@@ -630,15 +651,26 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
         (long long)(M / xps_big::TM) * (N / xps_big::TN) >= big_min_tiles() &&
         big_plain(A, ra, AK ? M : K) && big_plain(B, rb, BK ? N : K) && (!A2 || (big_plain(A2, ra, AK ? M : K2) && big_plain(B2, rb, BK ? N : K2))) &&
         rc.rpg >= M) {
-        static const bool ready = big_prepare(gemm_big_kernel<AK, BK, false>, BIG_LDS) && big_prepare(gemm_big_kernel<AK, BK, true>, BIG_LDS32);
+        static const bool ready = big_prepare(gemm_big_kernel<AK, BK, false, 0>, BIG_LDS) && big_prepare(gemm_big_kernel<AK, BK, false, 1>, BIG_LDS) &&
+                                  big_prepare(gemm_big_kernel<AK, BK, false, 2>, BIG_LDS) && big_prepare(gemm_big_kernel<AK, BK, false, 3>, BIG_LDS) &&
+                                  big_prepare(gemm_big_kernel<AK, BK, true>, BIG_LDS32);
         if (ready) {
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN));
             if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0)
                 hipLaunchKernelGGL((gemm_big_kernel<AK, BK, true>), bgrid, dim3(xps_big::NTHR), BIG_LDS32, st,
-                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate);
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
+            else if (fmt == 0)
+                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false, 0>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
+            else if (fmt == 1)
+                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false, 1>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
+            else if (fmt == 2)
+                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false, 2>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
             else
-                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
-                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate);
+                hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false, 3>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
             return hipGetLastError() == hipSuccess ? 0 : -1;
         }
     }
@@ -669,7 +701,12 @@ extern "C" int xps_gemm_nt_f32(const float* A, const xps_rowmap* ra_, const floa
     XPS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     if (M == 0 || N == 0) return XPS_OK;
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
-    if (launch_gemm<true, true>(A, ra, B, rb, nullptr, nullptr, 0, C, rc, bias, M, N, K, accumulate, (hipStream_t)stream)) {
+    const int lrc = launch_gemm<true, true>(A, ra, B, rb, nullptr, nullptr, 0, C, rc, bias, M, N, K, accumulate, (hipStream_t)stream);
+    if (lrc == -2) {
+        xps_set_error("xps_gemm_nt_f32: XPS_FMT_SPLIT4 operand needs bf16x3 mode, M > 16, 16-byte aligned rows and a contiguous extent that is a multiple of 4");
+        return XPS_E_INVALID;
+    }
+    if (lrc) {
         xps_set_error("xps_gemm_nt_f32: launch failed: %s", hipGetErrorString(hipGetLastError()));
         return XPS_E_HIP;
     }
@@ -683,7 +720,12 @@ extern "C" int xps_gemm_nn_f32(const float* A, const xps_rowmap* ra_, const floa
     XPS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     if (M == 0 || N == 0) return XPS_OK;
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
-    if (launch_gemm<true, false>(A, ra, B, rb, nullptr, nullptr, 0, C, rc, nullptr, M, N, K, accumulate, (hipStream_t)stream)) {
+    const int lrc = launch_gemm<true, false>(A, ra, B, rb, nullptr, nullptr, 0, C, rc, nullptr, M, N, K, accumulate, (hipStream_t)stream);
+    if (lrc == -2) {
+        xps_set_error("xps_gemm_nn_f32: XPS_FMT_SPLIT4 operand needs bf16x3 mode, M > 16, 16-byte aligned rows and a contiguous extent that is a multiple of 4");
+        return XPS_E_INVALID;
+    }
+    if (lrc) {
         xps_set_error("xps_gemm_nn_f32: launch failed: %s", hipGetErrorString(hipGetLastError()));
         return XPS_E_HIP;
     }
@@ -706,7 +748,15 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
         pm.B[i] = B[j]; pm.C[i] = C[j]; pm.bias[i] = bias ? bias[j] : nullptr;
         vb = vb && map_vec_ok(B[j], rb);
     }
-    const int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
+    int vecA = (int)map_vec_ok(A, ra), vecB = (int)vb;
+    int fA = split4_flag(A, ra, K), fB = 0;
+    for (int i = 0; i < nprob && fB >= 0; ++i) fB = split4_flag(B[i], rb, K);
+    if (fA < 0 || fB < 0 || ((fA | fB) && !bf_mode())) {
+        xps_set_error("xps_gemm_nt_multi_f32: XPS_FMT_SPLIT4 operand needs bf16x3 mode, 16-byte aligned rows and K %% 4 == 0");
+        return XPS_E_INVALID;
+    }
+    vecA |= fA; vecB |= fB;
+    const int fmt = (fA ? 1 : 0) | (fB ? 2 : 0);
     if (big_enabled() && M % xps_big::TM == 0 && N % xps_big::TN == 0 && K % BKT == 0 && K >= 64 && vb &&
         (long long)(M / xps_big::TM) * (N / xps_big::TN) * nprob >= big_min_tiles() &&
         big_plain(A, ra, M) && rb.rpg >= N && rc.rpg >= M) {
@@ -715,10 +765,10 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN) * nprob);
             if (big_deep_allowed() && K % 32 == 0)
                 hipLaunchKernelGGL(gemm_big_nt_multi_kernel<true>, bgrid, dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, A, ra.ld, pm,
-                                   rb.ld, rc.ld, N, K, nprob);
+                                   rb.ld, rc.ld, N, K, nprob, fmt);
             else
                 hipLaunchKernelGGL(gemm_big_nt_multi_kernel<false>, bgrid, dim3(xps_big::NTHR), BIG_LDS,
-                               (hipStream_t)stream, A, ra.ld, pm, rb.ld, rc.ld, N, K, nprob);
+                               (hipStream_t)stream, A, ra.ld, pm, rb.ld, rc.ld, N, K, nprob, fmt);
             XPS_CHECK_LAUNCH();
             return XPS_OK;
         }
@@ -748,7 +798,12 @@ extern "C" int xps_gemm_nn2_f32(const float* A1, const float* B1, int K1, const 
     XPS_CHECK_ARG(M >= 0 && N >= 0 && K1 >= 0 && K2 >= 0, "negative size");
     if (M == 0 || N == 0) return XPS_OK;
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
-    if (launch_gemm<true, false>(A1, ra, B1, rb, A2, B2, K2, C, rc, nullptr, M, N, K1, accumulate, (hipStream_t)stream)) {
+    const int lrc = launch_gemm<true, false>(A1, ra, B1, rb, A2, B2, K2, C, rc, nullptr, M, N, K1, accumulate, (hipStream_t)stream);
+    if (lrc == -2) {
+        xps_set_error("xps_gemm_nn2_f32: XPS_FMT_SPLIT4 operand needs bf16x3 mode, M > 16, 16-byte aligned rows and a contiguous extent that is a multiple of 4");
+        return XPS_E_INVALID;
+    }
+    if (lrc) {
         xps_set_error("xps_gemm_nn2_f32: launch failed: %s", hipGetErrorString(hipGetLastError()));
         return XPS_E_HIP;
     }
@@ -769,6 +824,7 @@ extern "C" int xps_gemm_tn_f32(const float* A, const xps_rowmap* ra_, const floa
     XPS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     if (M == 0 || N == 0) return XPS_OK;
     RowMap ra = to_rowmap(ra_), rb = to_rowmap(rb_), rc = to_rowmap(rc_);
+    XPS_CHECK_ARG(ra.fmt == 0 && rb.fmt == 0, "XPS_FMT_SPLIT4 operands: use xps_gemm_tn_grouped_f32");
     const int splits = (K > 0) ? tn_splits(M, N, K) : 1;
     if (workspace_bytes < xps_gemm_tn_f32_workspace(M, N, K) || !workspace) {
         xps_set_error("xps_gemm_tn_f32: workspace too small (%zu < %zu)", workspace_bytes,
@@ -854,8 +910,10 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         const int kq = (isbig[i] && q.K % 32 == 0) ? 32 : BKT;             // (32-deep stages of the big-tile kernel)
         P.kchunk = ((cdiv(q.K > 0 ? q.K : 1, sp) + kq - 1) / kq) * kq;
         P.tiles_n = cdiv(q.N, BN);
-        P.vecA = (int)map_vec_ok(q.A, P.ra);
-        P.vecB = (int)map_vec_ok(q.B, P.rb);
+        const int fA = split4_flag(q.A, P.ra, q.M), fB = split4_flag(q.B, P.rb, q.N);    // XPS_FMT_SPLIT4 operands
+        if (fA < 0 || fB < 0 || ((fA | fB) && !bf_mode())) return -2;
+        P.vecA = (int)map_vec_ok(q.A, P.ra) | fA;
+        P.vecB = (int)map_vec_ok(q.B, P.rb) | fB;
         P.slab_off = off;
         P.big = isbig[i] ? 1 : 0;
         if (isbig[i]) {
@@ -924,7 +982,8 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     TnGroup g;
     size_t fl = 0;
     if (build_group(probs, n, g, fl)) {
-        xps_set_error("xps_gemm_tn_grouped_f32: invalid problem list (1..%d problems, non-null pointers, M,N >= 1)", TN_MAXP);
+        xps_set_error("xps_gemm_tn_grouped_f32: invalid problem list (1..%d problems, non-null pointers, M,N >= 1; XPS_FMT_SPLIT4 "
+                      "operands: bf16x3 mode, 16-byte aligned rows, M / N multiples of 4)", TN_MAXP);
         return XPS_E_INVALID;
     }
     if (!workspace || workspace_bytes < fl * sizeof(float) + 16 || !aligned16(workspace)) {

@@ -49,12 +49,11 @@ struct BigLoader {
 };
 
 template <bool KC>
-__device__ inline void big_stage(const f32x4 (&v)[2], BfTile<256>& S, int tid) {
+__device__ inline void big_stage(const f32x4 (&v)[2], BfTile<256>& S, int tid, const bool pre) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         bf16x4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+        stage_split(v[r], pre, h, l);
         if (KC) {
             const int x = (tid >> 2) + 128 * r, k4 = (tid & 3) * 4;
             *reinterpret_cast<bf16x4*>(&S.hi[x][k4]) = h;
@@ -70,18 +69,21 @@ __device__ inline void big_stage(const f32x4 (&v)[2], BfTile<256>& S, int tid) {
 // Accumulates nkt k-tiles.  acc[i][j]: rows wm + 32 i, columns wn + 32 j of the block tile, wave w -> wm = 128 (w / 4),
 // wn = 64 (w % 4); C/D layout of the 32 x 32 MFMA.  csum (want_csum, [k][x] A operands only): running sums of this
 // thread's 4 x columns over its k rows (the bias gradient of the weight-gradient form), taken from the staging registers.
-template <bool AK, bool BK>
-__device__ inline void big_pipeline(f32x16 (&acc)[4][2], f32x4& csum, const bool want_csum, const BigLoader<AK>& la,
-                                    const BigLoader<BK>& lb, const int nkt, BigStage& S) {
+// PA / PB: the operand is XPS_FMT_SPLIT4 (compile-time: a run-time flag would put a branch into the k loop and keep the
+// scheduler from interleaving the staging with the MFMAs)
+template <bool AK, bool BK, bool PA, bool PB>
+__device__ inline void big_pipeline_t(f32x16 (&acc)[4][2], f32x4& csum, const bool want_csum, const BigLoader<AK>& la,
+                                      const BigLoader<BK>& lb, const int nkt, BigStage& S) {
+    constexpr bool preA = PA, preB = PB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
     f32x4 ra0[2], rb0[2], ra1[2], rb1[2];                 // k-tiles kt + 1 and kt + 2 in flight
     if (nkt > 0) {
         la.load(ra0, 0); lb.load(rb0, 0);
         if (nkt > 1) { la.load(ra1, 1); lb.load(rb1, 1); }
-        big_stage<AK>(ra0, S.a[0], tid);
-        big_stage<BK>(rb0, S.b[0], tid);
-        if (!AK && want_csum) csum += ra0[0] + ra0[1];
+        big_stage<AK>(ra0, S.a[0], tid, preA);
+        big_stage<BK>(rb0, S.b[0], tid, preB);
+        if (!AK && want_csum) csum += stage_values(ra0[0], preA) + stage_values(ra0[1], preA);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -104,13 +106,25 @@ __device__ inline void big_pipeline(f32x16 (&acc)[4][2], f32x4& csum, const bool
             }
         }
         if (kt + 1 < nkt) {
-            big_stage<AK>(ra1, S.a[buf ^ 1], tid);
-            big_stage<BK>(rb1, S.b[buf ^ 1], tid);
-            if (!AK && want_csum) csum += ra1[0] + ra1[1];
+            big_stage<AK>(ra1, S.a[buf ^ 1], tid, preA);
+            big_stage<BK>(rb1, S.b[buf ^ 1], tid, preB);
+            if (!AK && want_csum) csum += stage_values(ra1[0], preA) + stage_values(ra1[1], preA);
 #pragma unroll
             for (int r = 0; r < 2; ++r) { ra1[r] = ra0[r]; rb1[r] = rb0[r]; }
         }
         __syncthreads();
+    }
+}
+
+template <bool AK, bool BK>
+__device__ inline void big_pipeline(f32x16 (&acc)[4][2], f32x4& csum, const bool want_csum, const BigLoader<AK>& la,
+                                    const BigLoader<BK>& lb, const int nkt, BigStage& S, const bool preA, const bool preB) {
+    if (preA) {
+        if (preB) big_pipeline_t<AK, BK, true, true>(acc, csum, want_csum, la, lb, nkt, S);
+        else big_pipeline_t<AK, BK, true, false>(acc, csum, want_csum, la, lb, nkt, S);
+    } else {
+        if (preB) big_pipeline_t<AK, BK, false, true>(acc, csum, want_csum, la, lb, nkt, S);
+        else big_pipeline_t<AK, BK, false, false>(acc, csum, want_csum, la, lb, nkt, S);
     }
 }
 
@@ -168,12 +182,11 @@ struct BigLoader32 {
 };
 
 template <bool KC>
-__device__ inline void big_stage32(const f32x4 (&v)[4], Image32& S, int tid) {
+__device__ inline void big_stage32(const f32x4 (&v)[4], Image32& S, int tid, const bool pre) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         bf16x4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+        stage_split(v[r], pre, h, l);
         if (KC) {
             const int row = (tid >> 3) + 64 * r, kc = tid & 7, c4 = kc & 3;
             const int col = (((c4 >> 1) ^ ((row >> 3) & 1)) << 3) + ((c4 & 1) << 2);
@@ -243,14 +256,14 @@ __device__ inline void big_mma32(f32x16 (&acc)[4][2], const BigStage32& S, int b
 // nks 32-deep k-stages; same accumulation order per accumulator as the 16-deep pipelines (k-tile by k-tile)
 template <bool AK, bool BK>
 __device__ inline void big_pipeline32(f32x16 (&acc)[4][2], f32x4& csum, const bool want_csum, const BigLoader32<AK>& la,
-                                      const BigLoader32<BK>& lb, const int nks, BigStage32& S) {
+                                      const BigLoader32<BK>& lb, const int nks, BigStage32& S, const bool preA, const bool preB) {
     const int tid = threadIdx.x;
     if (nks <= 0) return;
     f32x4 va[4], vb[4];
     la.load(va, 0); lb.load(vb, 0);
-    big_stage32<AK>(va, S.a[0], tid);
-    big_stage32<BK>(vb, S.b[0], tid);
-    if (!AK && want_csum) csum += (va[0] + va[1]) + (va[2] + va[3]);
+    big_stage32<AK>(va, S.a[0], tid, preA);
+    big_stage32<BK>(vb, S.b[0], tid, preB);
+    if (!AK && want_csum) csum += (stage_values(va[0], preA) + stage_values(va[1], preA)) + (stage_values(va[2], preA) + stage_values(va[3], preA));
     __syncthreads();
     int ks = 0;
     for (; ks + 1 < nks; ++ks) {
@@ -258,9 +271,9 @@ __device__ inline void big_pipeline32(f32x16 (&acc)[4][2], f32x4& csum, const bo
         la.load(va, ks + 1); lb.load(vb, ks + 1);
         __builtin_amdgcn_sched_barrier(0);             // requests first: a whole stage of MFMAs hides them
         big_mma32<AK, BK>(acc, S, buf);
-        big_stage32<AK>(va, S.a[buf ^ 1], tid);
-        big_stage32<BK>(vb, S.b[buf ^ 1], tid);
-        if (!AK && want_csum) csum += (va[0] + va[1]) + (va[2] + va[3]);
+        big_stage32<AK>(va, S.a[buf ^ 1], tid, preA);
+        big_stage32<BK>(vb, S.b[buf ^ 1], tid, preB);
+        if (!AK && want_csum) csum += (stage_values(va[0], preA) + stage_values(va[1], preA)) + (stage_values(va[2], preA) + stage_values(va[3], preA));
         __syncthreads();
     }
     big_mma32<AK, BK>(acc, S, ks & 1);

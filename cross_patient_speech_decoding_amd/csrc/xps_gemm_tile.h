@@ -339,8 +339,31 @@ __device__ inline void bf_split(float x, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(x - (float)hi);
 }
 
+// Staging of one 16-byte vector.  fp32 operand: split its four values.  XPS_FMT_SPLIT4 operand (xps.h: the producer already
+// wrote hi[0..3] | lo[0..3] into the 16 bytes): no arithmetic at all.  `pre` is block-uniform.
+__device__ inline void stage_split(const f32x4& v, const bool pre, bf16x4& h, bf16x4& l) {
+    if (pre) {
+        // (element-wise shuffles: a bit_cast through a 2 x u64 vector returned the LOW half for both elements with this compiler)
+        const bf16x8 q = __builtin_bit_cast(bf16x8, v);
+        h = __builtin_shufflevector(q, q, 0, 1, 2, 3);
+        l = __builtin_shufflevector(q, q, 4, 5, 6, 7);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[j], a, b); h[j] = a; l[j] = b; }
+    }
+}
+// fp32 values of a staged vector (column sums of a split4 operand: hi + lo, within 2^-17 relative of the fp32 element)
+__device__ inline f32x4 stage_values(const f32x4& v, const bool pre) {
+    if (!pre) return v;
+    bf16x4 h, l;
+    stage_split(v, true, h, l);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (float)h[j] + (float)l[j];
+    return o;
+}
 template <bool KCONTIG, int W>
-__device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], BfTile<W>& S, int tid) {
+__device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], BfTile<W>& S, int tid, const bool pre) {
     using L = TileLoader<KCONTIG, W, true>;
     if (KCONTIG) {
         const int k4 = (tid % KL) * 4;
@@ -348,8 +371,7 @@ __device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::N
         for (int r = 0; r < L::NV; ++r) {
             const int x = tid / KL + L::XR * r;
             bf16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+            stage_split(v[r], pre, h, l);
             *reinterpret_cast<bf16x4*>(&S.hi[x][k4]) = h;
             *reinterpret_cast<bf16x4*>(&S.lo[x][k4]) = l;
         }
@@ -361,8 +383,7 @@ __device__ inline void bf_store(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::N
         for (int r = 0; r < L::NV; ++r) {
             const int k = tid / L::XL + L::KR * r;
             bf16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { __bf16 a, b; bf_split(v[r][j], a, b); h[j] = a; l[j] = b; }
+            stage_split(v[r], pre, h, l);
             *reinterpret_cast<bf16x4*>(&S.thi[k][x4]) = h;
             *reinterpret_cast<bf16x4*>(&S.tlo[k][x4]) = l;
         }
@@ -395,10 +416,10 @@ __device__ inline void bf_frag(const BfTile<W>& S, int x0, int lane, bf16x8& fh,
 // passes through them exactly once.  [k][x] form only: the thread's running sums are those of its 4 x columns over its
 // NV k rows; the 256 / XL threads that share the x group are folded by the kernel (lane shuffle + LDS).
 template <bool KCONTIG, int W>
-__device__ inline void bf_colsum(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], f32x4& cs) {
+__device__ inline void bf_colsum(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::NV], f32x4& cs, const bool pre) {
     if constexpr (!KCONTIG) {           // (never requested for [x][k] operands)
 #pragma unroll
-        for (int r = 0; r < TileLoader<KCONTIG, W, true>::NV; ++r) cs += v[r];
+        for (int r = 0; r < TileLoader<KCONTIG, W, true>::NV; ++r) cs += stage_values(v[r], pre);
     }
 }
 
@@ -415,6 +436,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
     const int li = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BKT - 1) / BKT;
+    const bool preA = (vecA & 2) != 0, preB = (vecB & 2) != 0;      // XPS_FMT_SPLIT4 operands (bit 1 of the vec flags)
 
     f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
@@ -424,9 +446,9 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
             if (MODE) { la.template load_fast<MODE == 2>(ra1, kbeg + BKT); lb.template load_fast<MODE == 2>(rb1, kbeg + BKT); }
             else { la.load(ra1, A, ra, m0, M, kbeg + BKT, kend, tid, vecA); lb.load(rb1, B, rb, n0, N, kbeg + BKT, kend, tid, vecB); }
         }
-        bf_store<AK, WM>(ra0, S.a[0], tid);
-        bf_store<BK, 128>(rb0, S.b[0], tid);
-        if (want_csum) bf_colsum<AK, WM>(ra0, csum);
+        bf_store<AK, WM>(ra0, S.a[0], tid, preA);
+        bf_store<BK, 128>(rb0, S.b[0], tid, preB);
+        if (want_csum) bf_colsum<AK, WM>(ra0, csum, preA);
     }
     __syncthreads();
 #ifdef XPS_GSTAMP
@@ -457,9 +479,9 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
         }
         GSTAMP(g2)
         if (kt + 1 < nkt) {
-            bf_store<AK, WM>(ra1, S.a[buf ^ 1], tid);
-            bf_store<BK, 128>(rb1, S.b[buf ^ 1], tid);
-            if (want_csum) bf_colsum<AK, WM>(ra1, csum);
+            bf_store<AK, WM>(ra1, S.a[buf ^ 1], tid, preA);
+            bf_store<BK, 128>(rb1, S.b[buf ^ 1], tid, preB);
+            if (want_csum) bf_colsum<AK, WM>(ra1, csum, preA);
 #pragma unroll
             for (int r = 0; r < LA::NV; ++r) ra1[r] = ra0[r];
 #pragma unroll

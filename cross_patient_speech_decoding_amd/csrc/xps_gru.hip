@@ -33,7 +33,7 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
                                  float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st);
 int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                  const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
-                                 int T, int B, int H, int ndir, void* workspace, hipStream_t st);
+                                 int T, int B, int H, int ndir, void* workspace, hipStream_t st, int split_out);
 
 namespace {
 
@@ -217,6 +217,8 @@ struct GruBwdParams {
     int has_drop;
     float drop_p, drop_scale;
     unsigned long long drop_seed;
+    // != 0 (resident bf16x3 kernels only): dgi / dghn are written as XPS_FMT_SPLIT4 groups (xps.h) for the GEMMs that read them
+    int split_out;
 };
 
 // Backward through time.  Per step: (1) lane-parallel gate gradients from the saved
@@ -812,6 +814,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_bwd_resident_kernel(GruBwdPara
                 dan4 = make_float4(o_dan[0], o_dan[1], o_dan[2], o_dan[3]);
             }
             pend[e * 4 + 0] = dar; pend[e * 4 + 1] = daz; pend[e * 4 + 2] = dan4; pend[e * 4 + 3] = danr;
+            if (BF && p.split_out) {        // the only readers are GEMMs: hand them the hi / lo split (same 16 bytes per group)
+                auto pack = [](const float4& v) {
+                    const f32x4 o = split4_pack((f32x4){v.x, v.y, v.z, v.w});
+                    return make_float4(o[0], o[1], o[2], o[3]);
+                };
+                pend[e * 4 + 0] = pack(dar); pend[e * 4 + 1] = pack(daz); pend[e * 4 + 2] = pack(dan4); pend[e * 4 + 3] = pack(danr);
+            }
             if constexpr (BF) {
                 auto put = [&](const float4& v, int col) {
                     bf16x4 sh, sl;
@@ -990,8 +999,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruStepFwd p) {
         }
         auto stage = [&](const f32x4 (&va)[LA::NV], const f32x4 (&vb)[LB::NV], int buf) {
             if constexpr (BF) {
-                bf_store<true, 128>(va, mem.st.a[buf], tid);
-                bf_store<true, 128>(vb, mem.st.b[buf], tid);
+                bf_store<true, 128>(va, mem.st.a[buf], tid, false);
+                bf_store<true, 128>(vb, mem.st.b[buf], tid, false);
             } else {
                 la.store(va, mem.As[buf], tid);
                 lb.store(vb, mem.Bs[buf], tid);
@@ -1342,7 +1351,7 @@ extern "C" size_t xps_gru_seq_bwd_f32_workspace(int T, int B, int H, int ndir) {
 static int gru_seq_bwd_impl(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                             const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                             int T, int B, int H, int ndir, int has_drop, float drop_p, unsigned long long drop_seed,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            void* workspace, size_t workspace_bytes, void* stream, int split_out = 0);
 
 extern "C" int xps_gru_seq_bwd_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                    const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
@@ -1361,11 +1370,30 @@ extern "C" int xps_gru_seq_bwd_drop_f32(const float* dy, const float* dhn, const
                             workspace, workspace_bytes, stream);
 }
 
+extern "C" int xps_gru_seq_bwd_split4_supported(int T, int B, int H, int ndir) {
+    if (T < 1 || B < 1 || (ndir != 1 && ndir != 2) || xps_internal_gemm_mode() != 1) return 0;
+    if (cluster_shape_ok(T, B, H, ndir)) return 1;
+    return xps_gru_seq_fused_dropout_supported(T, B, H, ndir);        // the register-resident kernels (H = 64 / 128)
+}
+
+extern "C" int xps_gru_seq_bwd_split4_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                                          const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                                          int T, int B, int H, int ndir, float drop_p, uint64_t drop_seed,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "0 <= p < 1");
+    XPS_CHECK_ARG(drop_p == 0.f || (dy && xps_gru_seq_fused_dropout_supported(T, B, H, ndir) && !cluster_shape_ok(T, B, H, ndir)),
+                  "fused dropout: dy must be given and the shape must be on the resident kernels");
+    return gru_seq_bwd_impl(dy, dhn, y_ext, saved, w_hh, w_hh_t, dgi, dghn, dh0, T, B, H, ndir, drop_p > 0.f ? 1 : 0, drop_p,
+                            (unsigned long long)drop_seed, workspace, workspace_bytes, stream, 1);
+}
+
 static int gru_seq_bwd_impl(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                             const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                             int T, int B, int H, int ndir, int has_drop, float drop_p, unsigned long long drop_seed,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            void* workspace, size_t workspace_bytes, void* stream, int split_out) {
     XPS_CHECK_ARG(y_ext && saved && w_hh && w_hh_t && dgi && dghn, "null argument");
+    XPS_CHECK_ARG(!split_out || xps_gru_seq_bwd_split4_supported(T, B, H, ndir),
+                  "XPS_FMT_SPLIT4 outputs: shape / precision mode not served (see xps_gru_seq_bwd_split4_supported)");
     XPS_CHECK_ARG(dy || dhn, "at least one of dy / dhn must be given");
     XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1, "T, B, H must be >= 1");
     XPS_CHECK_ARG(ndir == 1 || ndir == 2, "ndir must be 1 or 2");
@@ -1375,12 +1403,13 @@ static int gru_seq_bwd_impl(const float* dy, const float* dhn, const float* y_ex
             xps_set_error("xps_gru_seq_bwd_f32: workspace too small");
             return XPS_E_WORKSPACE;
         }
-        return xps_internal_gru_cluster_bwd(dy, dhn, y_ext, saved, w_hh_t, dgi, dghn, dh0, T, B, H, ndir, workspace, (hipStream_t)stream);
+        return xps_internal_gru_cluster_bwd(dy, dhn, y_ext, saved, w_hh_t, dgi, dghn, dh0, T, B, H, ndir, workspace, (hipStream_t)stream, split_out);
     }
     GruBwdParams p;
     p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir;
     p.has_drop = has_drop; p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
+    p.split_out = split_out;
     p.Hp = ((H + 15) / 16) * 16;
     p.ldg = 3 * p.Hp + 4;
     p.ldc = p.Hp + 4;
@@ -1393,6 +1422,7 @@ static int gru_seq_bwd_impl(const float* dy, const float* dhn, const float* y_ex
     const size_t lds_bytes = (size_t)GBM * (p.ldg + p.ldc) * sizeof(float);
     XPS_CHECK_ARG(lds_bytes <= 160 * 1024, "hidden size too large for the LDS-resident gradient tile");
     XPS_CHECK_ARG(!has_drop || vec, "fused dropout needs 16-byte aligned weights");
+    XPS_CHECK_ARG(!split_out || (vec && (H == 128 || H == 64)), "XPS_FMT_SPLIT4 outputs need the resident kernels (16-byte aligned weights)");
     if (H > 128 && use_step_path()) {
         if (!workspace || workspace_bytes < xps_gru_seq_bwd_f32_workspace(T, B, H, ndir) || !aligned16(workspace)) {
             xps_set_error("xps_gru_seq_bwd_f32: workspace too small or misaligned");

@@ -640,6 +640,7 @@ struct ClBwd {
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
     int ps_begin, ps_end, ps_total, handoff;
+    int split_out;              // != 0 (bf16x3 mode): dgi / dghn are written as XPS_FMT_SPLIT4 groups (xps.h) for the GEMMs that read them
 };
 
 // Same two wave roles as the forward kernel.  Sub-iteration q = (ps, round r, gate segment g): contraction waves accumulate
@@ -779,6 +780,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         }
         CL_FENCE();
         const unsigned go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
+        if (BF && p.split_out) {        // the only readers are GEMMs: hand them the hi / lo split instead of the fp32 values (same 16 bytes)
+            dar = split4_pack(dar); daz = split4_pack(daz); dan = split4_pack(dan); danr = split4_pack(danr);
+        }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dar), gr, go, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, 0);
@@ -1133,12 +1137,14 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
 
 int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                  const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
-                                 int T, int B, int H, int ndir, void* workspace, hipStream_t st) {
+                                 int T, int B, int H, int ndir, void* workspace, hipStream_t st, int split_out) {
     const ClPlan pl = cl_plan(B, H, ndir);
     if (!pl.ok) { xps_set_error("gru cluster backward: unsupported shape"); return XPS_E_INVALID; }
     const bool bf = xps_internal_gemm_mode() == 1;
     ClBwd p;
     p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
+    if (split_out && !bf) { xps_set_error("gru cluster backward: XPS_FMT_SPLIT4 outputs exist in bf16x3 mode only"); return XPS_E_INVALID; }
+    p.split_out = split_out;
     for (int d = 0; d < 2; ++d) p.w_hh_t[d] = w_hh_t[d < ndir ? d : 0];
     if (!cl_aligned16(dy) || !cl_aligned16(dhn) || !cl_aligned16(y_ext) || !cl_aligned16(saved) || !cl_aligned16(p.w_hh_t[0]) ||
         !cl_aligned16(p.w_hh_t[1]) || !cl_aligned16(dgi) || !cl_aligned16(dghn) || !cl_aligned16(dh0) || !cl_aligned16(workspace)) {

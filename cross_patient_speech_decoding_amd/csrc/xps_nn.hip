@@ -390,6 +390,16 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+// out = XPS_FMT_SPLIT4 image of dropout(x) (p = 0: of x itself): same values as dropout_kernel<true>, then split4_pack
+__global__ void split4_kernel(const float* __restrict__ x, float* __restrict__ out, long long nquad, float p, float scale,
+                              unsigned long long seed) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (long long)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * q);
+        if (p > 0.f) v = v * dropout_keep4(seed, q, p) * scale;
+        *reinterpret_cast<f32x4*>(out + 4 * q) = split4_pack(v);
+    }
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         out[i] = a[i] + b[i];
@@ -759,6 +769,17 @@ extern "C" int xps_dropout_f32(const float* x, float* out, float* mask, int64_t 
     else
         hipLaunchKernelGGL(dropout_kernel<false>, dim3(ew_grid((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, x, out, mask,
                            (long long)n, p, 1.0f / (1.0f - p), (unsigned long long)seed);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+extern "C" int xps_split4_f32(const float* x, float* out, int64_t n, float drop_p, uint64_t seed, void* stream) {
+    XPS_CHECK_ARG(x && out && n >= 0 && n % 4 == 0, "bad argument (n must be a multiple of 4)");
+    XPS_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "drop_p must be in [0, 1)");
+    XPS_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "buffers must be 16-byte aligned");
+    if (n == 0) return XPS_OK;
+    hipLaunchKernelGGL(split4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)(n / 4), drop_p,
+                       1.0f / (1.0f - drop_p), (unsigned long long)seed);
     XPS_CHECK_LAUNCH();
     return XPS_OK;
 }

@@ -337,6 +337,22 @@ def fused_dropout_supported(T, B, H, ndir):
     return v
 
 
+_split4_ok = {}
+
+
+def split4_supported(T, B, H, ndir):
+    """The BPTT kernels of this shape can write dgi / dghn as XPS_FMT_SPLIT4 groups (include/xps.h) in the current precision
+    mode: their readers (weight-gradient and input-gradient GEMMs) then stage them without conversion arithmetic, same bits.
+    XPS_SPLIT4=0: never."""
+    key = (T, B, H, ndir, lib().xps_get_gemm_precision(), lib().xps_get_gru_cluster_mode())
+    v = _split4_ok.get(key)
+    if v is None:
+        v = os.environ.get('XPS_SPLIT4', '1') != '0' and bool(lib().xps_gru_seq_bwd_split4_supported(T, B, H, ndir))
+        if len(_split4_ok) < 256:
+            _split4_ok[key] = v
+    return v
+
+
 def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     dev = gi.device
     y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
@@ -355,9 +371,10 @@ def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     return y_ext, saved
 
 
-def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=None):
+def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=None, split4=False):
     """BPTT kernel.  dy (T,B,ndir*H) or None, dhn (ndir,B,H) or None.  Returns dgi (ndir,T,B,3H),
-    dghn (ndir,T,B,H), dh0 (ndir,B,H) or None."""
+    dghn (ndir,T,B,H), dh0 (ndir,B,H) or None.  split4 (only where split4_supported): dgi / dghn hold XPS_FMT_SPLIT4
+    groups -- GEMM operands to be described with rowmap(..., fmt=1), not fp32 values."""
     dev = y_ext.device
     if dy is not None and not dy.is_contiguous():
         dy = dy.contiguous()
@@ -375,6 +392,13 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=Non
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
     nbytes = _gru_ws_bytes('xps_gru_seq_bwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
+    if split4:
+        fused = drop is not None and dy is not None
+        call('xps_gru_seq_bwd_split4_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
+             _ptr(dghn), _ptr(dh0), T, B, H, ndir, float(drop[0]) if fused else 0.0, int(drop[1]) if fused else 0, _ptr(ws), nbytes,
+             _stream())
+        _note_gru_status(ws, T, B, H, ndir)
+        return dgi, dghn, dh0
     if drop is not None and dy is not None:
         # dy is the gradient w.r.t. the dropped output of the forward kernel: the decisions are re-made while it is loaded
         call('xps_gru_seq_bwd_drop_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
@@ -386,9 +410,10 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=Non
     return dgi, dghn, dh0
 
 
-def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H, ndir):
+def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H, ndir, fmt=0):
     """dW_hh = dgh^T h_prev and db_hh = colsum(dgh) as grouped-TN problems.  h_prev(t) are slots of
-    y_ext (forward: slots 0..T-1, reverse: slots 2..T+1); the r,z rows of dgh are dgi's, the n rows dghn."""
+    y_ext (forward: slots 0..T-1, reverse: slots 2..T+1); the r,z rows of dgh are dgi's, the n rows dghn.
+    fmt = 1: dgi / dghn are XPS_FMT_SPLIT4 operands (_gru_backward(split4=True))."""
     dev = y_ext.device
     ldy = ndir * H
     probs, rets = [], []
@@ -401,9 +426,9 @@ def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H
             rw, rb = dw, db
         first_slot = 0 if d == 0 else 2
         hprev = y_ext.view(-1)[first_slot * B * ldy + d * H:]
-        probs.append(tn_problem(dgi[d], hprev, dw, 2 * H, H, T * B, ra=rowmap(3 * H), rb=rowmap(ldy), rc=rowmap(H),
+        probs.append(tn_problem(dgi[d], hprev, dw, 2 * H, H, T * B, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(ldy), rc=rowmap(H),
                                 colsum_out=db, accumulate=acc_w))
-        probs.append(tn_problem(dghn[d], hprev, dw[2 * H:], H, H, T * B, ra=rowmap(H), rb=rowmap(ldy), rc=rowmap(H),
+        probs.append(tn_problem(dghn[d], hprev, dw[2 * H:], H, H, T * B, ra=rowmap(H, fmt=fmt), rb=rowmap(ldy), rc=rowmap(H),
                                 colsum_out=db[2 * H:], accumulate=acc_w))
         rets.append((rw, rb))
     return probs, rets
@@ -449,7 +474,35 @@ class GRURecurFn(torch.autograd.Function):
 HN_NONE, HN_STACK, HN_SUM = 0, 1, 2
 
 
-class GRULayerDropFn(torch.autograd.Function):
+FMT_X_SPLIT4, FMT_Y_SPLIT4 = 1, 2
+
+
+def split4_mode():
+    """XPS_FMT_SPLIT4 operands are in use: bf16x3 product mode and not switched off (XPS_SPLIT4=0)."""
+    return lib().xps_get_gemm_precision() == 1 and os.environ.get('XPS_SPLIT4', '1') != '0'
+
+
+def layer_output_split4_ok(T, B, H, ndir, drop_p):
+    """A GRU layer whose dropped output is read by the NEXT layer's GEMMs only (input projection, dW_ih) can write it as
+    XPS_FMT_SPLIT4 groups in the dropout pass it runs anyway (shapes whose recurrence kernels do not fuse the dropout)."""
+    return bool(drop_p and drop_p > 0.0 and split4_mode() and (ndir * H) % 4 == 0 and not fused_dropout_supported(T, B, H, ndir))
+
+
+def _presplit_weights_ok(rows, In, H3):
+    """Pre-splitting W_ih (one small launch per matrix and forward pass) pays when the projection / input-gradient GEMMs
+    that read it are large (configs[3] layer 1: 40960 x 1536 x 1024); XPS_SPLIT4_WEIGHTS=0: never."""
+    return (split4_mode() and In % 4 == 0 and rows >= 4096 and In * H3 >= (1 << 19)
+            and os.environ.get('XPS_SPLIT4_WEIGHTS', '1') != '0')
+
+
+def split4(x, drop_p=0.0, seed=0):
+    """XPS_FMT_SPLIT4 image of dropout(x) (drop_p = 0: of x): a GEMM input operand for rowmap(..., fmt=1), not fp32 values."""
+    out = torch.empty_like(x)
+    call('xps_split4_f32', _ptr(x), _ptr(out), x.numel(), float(drop_p), int(seed), _stream())
+    return out
+
+
+class GRULayerFmtFn(torch.autograd.Function):
     """One (bi)directional GRU layer over a time-major input x (T, B, In):
     input projection GEMMs for all steps + fused recurrence; backward = BPTT kernel + ONE grouped
     launch for all six weight/bias gradients.  weights: per direction (w_ih, w_hh, b_ih, b_hh).
@@ -458,20 +511,27 @@ class GRULayerDropFn(torch.autograd.Function):
     the backward gets ONE (B, H) gradient for both directions); HN_NONE: None (inner layers)."""
 
     @staticmethod
-    def forward(ctx, x, ndir, hn_mode, drop_p, *wb):
+    def forward(ctx, x, ndir, hn_mode, drop_p, fmt, *wb):
         """drop_p > 0: the layer's output goes through inverted dropout (torch.nn.GRU's inter-layer dropout), fused into the
-        recurrence kernels where they support it (fused_dropout_supported), else a separate pass; hn stays undropped."""
+        recurrence kernels where they support it (fused_dropout_supported), else a separate pass; hn stays undropped.
+        fmt: FMT_X_SPLIT4 -- x holds XPS_FMT_SPLIT4 groups (the previous layer wrote them); FMT_Y_SPLIT4 -- write the
+        dropped output that way (only where layer_output_split4_ok): such a tensor is a GEMM operand, not fp32 values."""
         ctx.set_materialize_grads(False)
         _need_gpu(x, *wb)
         x = x.contiguous()
         T, B, In = x.shape
+        x_fmt = 1 if (fmt & FMT_X_SPLIT4) else 0
         w_ih = [wb[4 * d + 0].contiguous() for d in range(ndir)]
         w_hh = [wb[4 * d + 1].contiguous() for d in range(ndir)]
         b_ih = [wb[4 * d + 2].contiguous() for d in range(ndir)]
         b_hh = [wb[4 * d + 3].contiguous() for d in range(ndir)]
         H = w_hh[0].shape[1]
         gi = torch.empty(ndir, T, B, 3 * H, dtype=_f32, device=x.device)
-        ra, rb, rc = rowmap(In), rowmap(In), rowmap(3 * H)          # all directions in ONE launch
+        # large layers: W_ih split once per forward pass (its readers: this projection and the backward's input gradient)
+        w_fmt = 1 if _presplit_weights_ok(T * B, In, 3 * H) else 0
+        if w_fmt:
+            w_ih = [split4(w) for w in w_ih]
+        ra, rb, rc = rowmap(In, fmt=x_fmt), rowmap(In, fmt=w_fmt), rowmap(3 * H)          # all directions in ONE launch
         call('xps_gemm_nt_multi_f32', _ptr(x), C.byref(ra), _ptr_array(w_ih), C.byref(rb), _ptr_array([gi[d] for d in range(ndir)]),
              C.byref(rc), _ptr_array(b_ih), ndir, T * B, 3 * H, In, _stream())
         save = any(ctx.needs_input_grad)
@@ -489,6 +549,7 @@ class GRULayerDropFn(torch.autograd.Function):
             ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
         ctx.params = wb
         ctx.dims = (T, B, H, ndir, In, hn_mode)
+        ctx.fmts = (x_fmt, w_fmt)
         # y: per-step outputs (a view of y_ext: slots 1..T); hn: final hidden state of each direction
         # (forward: t = T-1, reverse: t = 0), returned separately so that a consumer of the final state
         # only (the seq2seq encoder) sends back a small gradient instead of a zero-padded (T, B, .) one
@@ -497,8 +558,13 @@ class GRULayerDropFn(torch.autograd.Function):
             y = y_drop
         elif drop is not None:                  # shapes without the fused path: the same decisions in a separate pass
             out = torch.empty(T, B, ndir * H, dtype=_f32, device=x.device)
-            call('xps_dropout_f32', _ptr(y), _ptr(out), None, out.numel(), drop[0], drop[1], _stream())
+            if fmt & FMT_Y_SPLIT4:              # same decisions and values, written as the hi / lo split the next layer's GEMMs stage
+                call('xps_split4_f32', _ptr(y), _ptr(out), out.numel(), drop[0], drop[1], _stream())
+            else:
+                call('xps_dropout_f32', _ptr(y), _ptr(out), None, out.numel(), drop[0], drop[1], _stream())
             y = out
+        if (fmt & FMT_Y_SPLIT4) and (drop is None or ctx.drop_fused):
+            raise ValueError('FMT_Y_SPLIT4: only with a separate dropout pass (see layer_output_split4_ok)')
         if hn_mode == HN_NONE:
             hn = None
         elif hn_mode == HN_SUM:
@@ -514,18 +580,21 @@ class GRULayerDropFn(torch.autograd.Function):
             dhn = dhn.unsqueeze(0).expand(ndir, B, H).contiguous()
         x, y_ext, saved, *w = ctx.saved_tensors
         w_ih, w_hh = w[:ndir], w[ndir:]
+        x_fmt, w_fmt = ctx.fmts
         wb = ctx.params
         if ctx.drop is not None and dy is not None and not ctx.drop_fused:
             dyc = dy.contiguous()
             dyd = torch.empty_like(dyc)
             call('xps_dropout_f32', _ptr(dyc), _ptr(dyd), None, dyc.numel(), ctx.drop[0], ctx.drop[1], _stream())
             dy = dyd
-        dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False, ctx.drop if ctx.drop_fused else None)
+        fmt = 1 if split4_supported(T, B, H, ndir) else 0        # dgi / dghn only feed GEMMs: pre-split operands, same bits
+        dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False, ctx.drop if ctx.drop_fused else None,
+                                     split4=bool(fmt))
         dev = x.device
         # weight gradients first: on the side stream they depend on the recurrence kernel only, so they start
         # together with the input-gradient GEMM below instead of after it (and are out of the way earlier)
         probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_ext, [wb[4 * d + 1] for d in range(ndir)],
-                                                  [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir)
+                                                  [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir, fmt)
         rets_ih = []
         for d in range(ndir):
             dw, acc_w, rw = _grad_target(wb[4 * d + 0], (3 * H, In), dev)
@@ -534,7 +603,8 @@ class GRULayerDropFn(torch.autograd.Function):
                 dw, acc_w = torch.empty(3 * H, In, dtype=_f32, device=dev), False
                 db = torch.empty(3 * H, dtype=_f32, device=dev)
                 rw, rb = dw, db
-            probs.append(tn_problem(dgi[d], x, dw, 3 * H, In, T * B, colsum_out=db, accumulate=acc_w))
+            probs.append(tn_problem(dgi[d], x, dw, 3 * H, In, T * B, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(In, fmt=x_fmt),
+                                    colsum_out=db, accumulate=acc_w))
             rets_ih.append((rw, rb))
         direct = all(r[0] is None and r[1] is None for r in rets_ih + rets_hh)
         _launch_weight_grads(lambda st: gemm_tn_grouped(probs, dev, st), dev, (dgi, dghn, x, y_ext), direct)
@@ -542,15 +612,28 @@ class GRULayerDropFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, In, dtype=_f32, device=dev)
             if ndir == 2:       # both directions summed in registers: one launch, no accumulate pass over dx
-                ra, rb, rc = rowmap(3 * H), rowmap(In), rowmap(In)
+                ra, rb, rc = rowmap(3 * H, fmt=fmt), rowmap(In, fmt=w_fmt), rowmap(In)
                 call('xps_gemm_nn2_f32', _ptr(dgi[0]), _ptr(w_ih[0]), 3 * H, _ptr(dgi[1]), _ptr(w_ih[1]), 3 * H,
                      C.byref(ra), C.byref(rb), _ptr(dx), C.byref(rc), T * B, In, 0, _stream())
             else:
-                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H)
+                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(In, fmt=w_fmt))
         grads = []
         for d in range(ndir):
             grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
+
+
+class GRULayerDropFn(torch.autograd.Function):
+    """GRULayerFmtFn on plain fp32 tensors: (x, ndir, hn_mode, drop_p, *weights)."""
+
+    @staticmethod
+    def forward(ctx, x, ndir, hn_mode, drop_p, *wb):
+        return GRULayerFmtFn.forward(ctx, x, ndir, hn_mode, drop_p, 0, *wb)
+
+    @staticmethod
+    def backward(ctx, dy, dhn):
+        g = GRULayerFmtFn.backward(ctx, dy, dhn)
+        return g[:4] + g[5:]
 
 
 class GRULayerFn(torch.autograd.Function):

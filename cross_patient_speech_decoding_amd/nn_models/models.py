@@ -148,11 +148,18 @@ class EncoderRNN(nn.Module):
         rnn = self.rnn
         L = rnn.num_layers
         y = x
+        fmt = 0
         for l in range(L):
             # inter-layer dropout (all layers but the last, training only) travels with the layer: its recurrence kernels
             # write the dropped output and re-make the decisions in the backward pass (no separate passes over y / dy)
             p_drop = float(rnn.dropout) if (l < L - 1 and self.training) else 0.0
-            y, last = XF.GRULayerDropFn.apply(y, 2, XF.HN_SUM if l == L - 1 else XF.HN_NONE, p_drop, *_gru_layer_weights(rnn, l, 2))
+            # a dropped output that only the next layer's GEMMs read is written as XPS_FMT_SPLIT4 groups (include/xps.h) where
+            # the layer runs a dropout pass of its own (H = 512 / 500): those GEMMs then stage it without conversion arithmetic
+            T_, B_ = y.shape[0], y.shape[1]
+            out_split = XF.layer_output_split4_ok(T_, B_, rnn.hidden_size, 2, p_drop)
+            y, last = XF.GRULayerFmtFn.apply(y, 2, XF.HN_SUM if l == L - 1 else XF.HN_NONE, p_drop,
+                                             fmt | (XF.FMT_Y_SPLIT4 if out_split else 0), *_gru_layer_weights(rnn, l, 2))
+            fmt = XF.FMT_X_SPLIT4 if out_split else 0
         return y, last                                    # last = h_fwd(T-1) + h_bwd(0)
 
     def forward(self, x):

@@ -46,8 +46,17 @@ typedef struct xps_rowmap {
     int64_t gs;    /* stride between groups of rows            */
     int64_t ld;    /* stride between rows inside a group       */
     int32_t rpg;   /* rows per group (>= 1)                    */
-    int32_t pad_;
+    int32_t fmt;   /* XPS_FMT_F32 (0) or XPS_FMT_SPLIT4 (1): element format of a GEMM INPUT operand (ignored for outputs) */
 } xps_rowmap;
+/* XPS_FMT_SPLIT4: every aligned group of four consecutive fp32 elements (16 bytes, along the contiguous index) holds the
+ * bf16 split of its values instead: bytes 0-7 = hi[0..3] = bf16(x[0..3]), bytes 8-15 = lo[0..3] = bf16(x[j] - hi[j]) -- exactly
+ * what the bf16x3 tile kernels compute while they stage an fp32 operand.  A producer that owns the split anyway (the BPTT
+ * kernels, xps_dropout_f32 / xps_split4_f32 with split_out) writes it once; the GEMM entry points (nt / nn / nn2 / nt_multi /
+ * tn_grouped, bf16x3 mode only) then stage the operand without any conversion arithmetic and return the SAME BITS as for
+ * the fp32 operand (a bias gradient folded from a split4 A operand sums hi + lo: within 2^-17 relative of the fp32 sum).
+ * Needs 16-byte aligned operands, leading dimensions and the contiguous extent multiples of 4; else XPS_E_INVALID. */
+#define XPS_FMT_F32 0
+#define XPS_FMT_SPLIT4 1
 
 const char* xps_last_error(void);
 int xps_abi_version(void);
@@ -177,6 +186,15 @@ int xps_gru_seq_bwd_drop_f32(const float* dy, const float* dhn, const float* y_e
                              const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                              int T, int B, int H, int ndir, float drop_p, uint64_t drop_seed,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward with dgi / dghn written as XPS_FMT_SPLIT4 groups (see xps_rowmap): their only readers are GEMMs (weight
+ * gradients, the layer's input gradient), and the BPTT kernels hold the bf16 hi / lo split of every gate gradient anyway.
+ * bf16x3 mode; cluster-persistent shapes (256 < H <= 512) and the register-resident ones (H = 64 / 128):
+ * xps_gru_seq_bwd_split4_supported.  drop_p > 0: the fused inter-layer dropout of xps_gru_seq_bwd_drop_f32 (resident shapes). */
+int xps_gru_seq_bwd_split4_supported(int T, int B, int H, int ndir);
+int xps_gru_seq_bwd_split4_f32(const float* dy, const float* dhn, const float* y_ext, const float* saved,
+                               const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
+                               int T, int B, int H, int ndir, float drop_p, uint64_t drop_seed,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 int xps_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
 /* 1..4 equally shaped matrices in one launch (host arrays of device pointers): both directions' W_hh^T */
@@ -276,6 +294,11 @@ int xps_decoder_select_f32(const float* h, const float* w_fc, const float* b_fc,
  * regenerates the decisions by the same call on the incoming gradient (same seed), no mask tensor exists;
  * with a stored mask the backward is xps_mask_scale_f32.                                                 */
 int xps_dropout_f32(const float* x, float* out, float* mask, int64_t n, float p, uint64_t seed, void* stream);
+/* out = the XPS_FMT_SPLIT4 image (see xps_rowmap) of dropout(x) -- drop_p = 0: of x itself; else the values xps_dropout_f32(x,
+ * seed) would write, decisions regenerated in the backward by xps_dropout_f32 on the gradient as before.  For tensors that only
+ * GEMMs read (a layer input that exists only as the dropped output of the previous layer, weights once per forward pass):
+ * the tile kernels then stage them without conversion arithmetic.  n % 4 == 0, 16-byte aligned buffers. */
+int xps_split4_f32(const float* x, float* out, int64_t n, float drop_p, uint64_t seed, void* stream);
 /* out = x * mask * scale */
 int xps_mask_scale_f32(const float* x, const float* mask, float scale, float* out, int64_t n, void* stream);
 /* out = a + b (elementwise) */
