@@ -491,7 +491,7 @@ def layer_output_split4_ok(T, B, H, ndir, drop_p):
 def _presplit_weights_ok(rows, In, H3):
     """Pre-splitting W_ih (one small launch per matrix and forward pass) pays when the projection / input-gradient GEMMs
     that read it are large (configs[3] layer 1: 40960 x 1536 x 1024); XPS_SPLIT4_WEIGHTS=0: never."""
-    return (split4_mode() and In % 4 == 0 and rows >= 4096 and In * H3 >= (1 << 19)
+    return (split4_mode() and In % 4 == 0 and rows >= 4096 and In * H3 >= int(os.environ.get('XPS_SPLIT4_WEIGHTS_MIN', 1 << 19))
             and os.environ.get('XPS_SPLIT4_WEIGHTS', '1') != '0')
 
 
