@@ -230,3 +230,35 @@ def test_encoder_stack_with_split4_tensors_equals_the_fp32_tensor_path(H, In, mo
     # the bias gradients are not just close, they are the exact column sums of hi + lo: within 1e-6 relative of the fp32 sums here
     rel = max(((g1[k] - g0[k]).abs().max() / g0[k].abs().max()).item() for k in g0 if 'bias' in k)
     assert rel <= 1e-5
+
+
+@pytest.mark.parametrize('M,N,K,nprob', [(40960, 384, 256, 2), (40960, 384, 100, 2), (4100, 96, 64, 3), (8192, 256, 32, 1),
+                                         (5000, 160, 200, 2)])
+def test_weight_stationary_projection_equals_the_tile_kernels_bitwise(M, N, K, nprob, monkeypatch):
+    """proj_ws_kernel (weights of a 256-column slice resident in registers, A streamed once per slice; csrc/xps_gemm.hip) issues
+    the same products in the same order per accumulator as the tile kernels: identical bits, for fp32 and XPS_FMT_SPLIT4
+    operands, ragged row counts, K that is not a multiple of 32, column slices that straddle problems or are partly idle."""
+    F = XF()
+    A = rnd(M, K, seed=1)
+    W = [rnd(N, K, seed=10 + i, scale=K ** -0.5) for i in range(nprob)]
+    bs = [rnd(N, seed=20 + i) for i in range(nprob)]
+
+    def run(a, w, fa, fb):
+        outs = [torch.full((M, N), float('nan'), device='cuda') for _ in range(nprob)]
+        ra, rb, rc = rowmap(K, fmt=fa), rowmap(K, fmt=fb), rowmap(N)
+        call('xps_gemm_nt_multi_f32', a.data_ptr(), C.byref(ra), F._ptr_array(w), C.byref(rb), F._ptr_array(outs), C.byref(rc),
+             F._ptr_array(bs), nprob, M, N, K, F._stream())
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv('XPS_PROJ_WS', '0')
+    ref = run(A, W, 0, 0)
+    monkeypatch.setenv('XPS_PROJ_WS', '1')
+    for fa, fb in [(0, 0), (1, 0), (1, 1)]:
+        got = run(split4(A) if fa else A, [split4(w) for w in W] if fb else W, fa, fb)
+        for i in range(nprob):
+            assert torch.equal(got[i], ref[i]), (fa, fb, i)
+    # and against fp64 (an indexing mistake common to both paths would pass the comparison above)
+    ref64 = A.double() @ W[-1].double().T + bs[-1].double()
+    bound = 1.6e-5 * (A.abs().double() @ W[-1].abs().double().T) + 1e-6
+    assert bool(((ref[-1].double() - ref64).abs() <= bound).all())
