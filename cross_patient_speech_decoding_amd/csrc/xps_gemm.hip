@@ -177,8 +177,10 @@ __global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_
 // Measured (tools/bench_proj.py, cfg-2 shapes, 2 directions): 40960 x 384 x 256: 90 -> 73-83 us; K = 100: 48 -> 42 us;
 // 40960 x 192 x 128: 41 -> 27 us.  Builds without the C stores / without the MFMAs run the first shape in 58 / 42-50 us: the
 // phases of a tile (stage, multiply, store) do not overlap -- all eight waves move in step through one barrier per tile; the
-// next step is to issue a tile's stores between the MFMAs of the following tile (needs the 32 registers the KT = 16 build
-// does not have: 248 used) or two independent wave teams per CU.
+// software pipeline that was tried next -- 32-row tiles (to make room for a pending tile beside 128 weight registers), the next
+// tile's split + LDS stores and the previous tile's C stores spread over the k-steps of the current one, one barrier per tile;
+// same bits, 244 registers -- ran SLOWER (82-93 us): one accumulator chain per wave instead of two, twice the barriers per
+// byte.  Left for the next round: two independent wave teams per CU (anti-phase), or the pipeline with 64-row tiles for K <= 192.
 template <int KT>
 __global__ __launch_bounds__(512, 1) void proj_ws_kernel(const float* __restrict__ A, long long lda, NtMulti pm, long long ldb, long long ldc,
                                                          int M, int N, int K, int nprob, int preA, int preB) {
