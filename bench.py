@@ -365,8 +365,10 @@ def fp32_record(c, dev, steps=20, warm=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    # defaults: 200 timed steps (~0.2 s) -- with 20 (a 22-ms window) one host-side hiccup of a few ms moved the headline by 10-25 %
+    # (1.04-1.06 ms/step typical, single runs at 1.27-1.6 seen); the enqueue path leaves the host ~15 % of slack per step
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--headline-only', action='store_true', help='skip the configs[3] shard and fp32 sub-records')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default=None,

@@ -37,7 +37,7 @@ namespace {
 #ifndef XPS_BF_MI1_WAVES
 #define XPS_BF_MI1_WAVES XPS_GEMM_WAVES
 #endif
-template <bool AK, bool BK, int MI, bool EDGE = false, bool BF = false>
+template <bool AK, bool BK, int MI, bool EDGE = false, bool BF = false, bool PRE = false>      // PRE: XPS_FMT_SPLIT4 operands (bf16x3 only)
 __global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_WAVES) void gemm_f32_kernel(
     const float* __restrict__ A, RowMap ra, const float* __restrict__ B, RowMap rb,
     const float* __restrict__ A2, const float* __restrict__ B2, int K2,
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_
     zero_acc<MI>(acc);
     float nocs = 0.f;
     f32x4 nocs4 = {0.f, 0.f, 0.f, 0.f};
-    gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, nocs4, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem);
-    if (A2) gemm_accumulate_any<AK, BK, MI, EDGE, BF>(acc, nocs, nocs4, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, mem);
+    gemm_accumulate_any<AK, BK, MI, EDGE, BF, PRE>(acc, nocs, nocs4, false, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem);
+    if (A2) gemm_accumulate_any<AK, BK, MI, EDGE, BF, PRE>(acc, nocs, nocs4, false, A2, ra, B2, rb, M, N, K2, m0, n0, 0, K2, vecA, vecB, mem);
     gemm_store<MI>(acc, C + (long long)z * slab_stride, rc, bias, M, N, m0, n0, accumulate);
 }
 
@@ -143,7 +143,7 @@ struct NtMulti {
     const float* bias[4];
     float* C[4];
 };
-template <int MI, bool EDGE = false, bool BF = false>
+template <int MI, bool EDGE = false, bool BF = false, bool PRE = false>
 __global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_WAVES) void gemm_nt_multi_kernel(
     const float* __restrict__ A, RowMap ra, NtMulti pm, RowMap rb, RowMap rc, int M, int N, int K, int nprob,
     int vecA, int vecB) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_
     zero_acc<MI>(acc);
     float nocs = 0.f;
     f32x4 nocs4 = {0.f, 0.f, 0.f, 0.f};
-    gemm_accumulate_any<true, true, MI, EDGE, BF>(acc, nocs, nocs4, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, mem);
+    gemm_accumulate_any<true, true, MI, EDGE, BF, PRE>(acc, nocs, nocs4, false, A, ra, pm.B[z], rb, M, N, K, m0, n0, 0, K, vecA, vecB, mem);
     gemm_store<MI>(acc, pm.C[z], rc, pm.bias[z], M, N, m0, n0, 0);
 }
 
@@ -339,7 +339,7 @@ __device__ inline void slab_decode(int e, int& row, int& col) {
     col = (wave & 1) * 64 + (ij & 1) * 32 + li;
 }
 
-template <bool EDGE, bool BF = false>
+template <bool EDGE, bool BF = false, bool PRE = false>
 __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(TnGroup g, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) TileMem<BF> mem;
     // Logical order, uniform groups (the weight gradients of a GRU layer: same K = T' x B rows for every problem):
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, XPS_GEMM_WAVES) void gemm_tn_grouped_kernel(Tn
     zero_acc<2>(acc);
     float csum = 0.f;
     f32x4 csum4 = {0.f, 0.f, 0.f, 0.f};
-    gemm_accumulate_any<false, false, 2, EDGE, BF>(acc, csum, csum4, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
+    gemm_accumulate_any<false, false, 2, EDGE, BF, PRE>(acc, csum, csum4, cs != nullptr, P.A, P.ra, P.B, P.rb, P.M, P.N, P.K, tm * BM, tn * BN,
                                                    kbeg, kend, P.vecA, P.vecB, mem);
     slab_store(acc, slab + (long long)tile * TN_TILE);
     if (BF && cs) {
@@ -802,8 +802,14 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
         }
     }
 #define XPS_LAUNCH_GEMM(MI_, EDGE_, BF_)                                                                              \
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, MI_, EDGE_, BF_>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, \
-                       bias, M, N, K, kchunk, 0LL, accumulate, vecA, vecB)
+    do {                                                                                                              \
+        if (BF_ && fmt)                                                                                               \
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, MI_, EDGE_, BF_, BF_>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, \
+                               bias, M, N, K, kchunk, 0LL, accumulate, vecA, vecB);                                   \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, MI_, EDGE_, BF_>), grid, dim3(256), 0, st, A, ra, B, rb, A2, B2, K2, C, rc, \
+                               bias, M, N, K, kchunk, 0LL, accumulate, vecA, vecB);                                   \
+    } while (0)
     const bool bf = bf_mode();
     if (use_small_tiles(M, N)) {
         dim3 grid(cdiv(N, BN) * cdiv(M, 64));
@@ -936,8 +942,14 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
         }
     }
 #define XPS_LAUNCH_NTM(MI_, EDGE_, BF_)                                                                                  \
-    hipLaunchKernelGGL((gemm_nt_multi_kernel<MI_, EDGE_, BF_>), dim3(cdiv(N, BN) * cdiv(M, 64 * MI_) * nprob), dim3(256), 0,   \
-                       (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB)
+    do {                                                                                                                 \
+        if (BF_ && fmt)                                                                                                  \
+            hipLaunchKernelGGL((gemm_nt_multi_kernel<MI_, EDGE_, BF_, BF_>), dim3(cdiv(N, BN) * cdiv(M, 64 * MI_) * nprob), dim3(256), 0, \
+                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);                        \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gemm_nt_multi_kernel<MI_, EDGE_, BF_>), dim3(cdiv(N, BN) * cdiv(M, 64 * MI_) * nprob), dim3(256), 0,    \
+                               (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);                        \
+    } while (0)
     const bool bf = bf_mode();
     if (use_small_tiles(M, N * nprob)) {
         const bool edge = (M % 64) || (N % BN);
@@ -1155,6 +1167,8 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     bool edge = false;
     for (int i = 0; i < n; ++i) edge = edge || (!g.p[i].big && ((probs[i].M % BM) || (probs[i].N % BN)));
     const bool bf = bf_mode();
+    bool anypre = false;                   // a 128-tile problem with an XPS_FMT_SPLIT4 operand: the kernel instantiation that reads the flags
+    for (int i = 0; i < n; ++i) anypre = anypre || (!g.p[i].big && ((g.p[i].vecA | g.p[i].vecB) & 2));
     if (g.total_blocks_big > 0) {
         static const bool ready = big_prepare(gemm_big_tn_kernel<false>, BIG_LDS) && big_prepare(gemm_big_tn_kernel<true>, BIG_LDS32);
         if (!ready) {
@@ -1175,7 +1189,11 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
         XPS_CHECK_LAUNCH();
     }
     if (g.total_blocks == 0) {
-    } else if (bf && edge)
+    } else if (bf && edge && anypre)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, true, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    else if (bf && anypre)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, true, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
+    else if (bf && edge)
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<true, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);
     else if (bf)
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<false, true>), dim3(g.total_blocks), dim3(256), 0, (hipStream_t)stream, g, (float*)workspace);

@@ -424,7 +424,11 @@ __device__ inline void bf_colsum(const f32x4 (&v)[TileLoader<KCONTIG, W, true>::
 }
 
 // same contract as gemm_pipeline (MODE 0 guarded / 1 interior / 2 predicated edge); csum: see bf_colsum
-template <bool AK, bool BK, int MI, int MODE>
+// ANYPRE = false: both operands are fp32 -- the k loop carries no operand-format flags at all (a run-time flag inside the loop
+// cost the fp32-operand path 2.4 % of the cfg-2 step and 4 % of its weight-gradient launch: the branches keep the scheduler
+// from interleaving staging and MFMAs; two loop copies inside one kernel raised its registers from 156 to 224).  ANYPRE = true
+// (a kernel instantiation of its own, launched when an operand is XPS_FMT_SPLIT4): formats from bit 1 of the vec flags.
+template <bool AK, bool BK, int MI, int MODE, bool ANYPRE = false>
 __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const bool want_csum,
                                         const TileLoader<AK, 64 * MI, true>& la, const TileLoader<BK, 128, true>& lb,
                                         const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
@@ -436,7 +440,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
     const int li = lane & 31, lk = lane >> 5;
     const int nkt = (kend - kbeg + BKT - 1) / BKT;
-    const bool preA = (vecA & 2) != 0, preB = (vecB & 2) != 0;      // XPS_FMT_SPLIT4 operands (bit 1 of the vec flags)
+    const bool preA = ANYPRE && (vecA & 2) != 0, preB = ANYPRE && (vecB & 2) != 0;
 
     f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];      // tiles kt+1 and kt+2 in flight
     if (nkt > 0) {
@@ -502,7 +506,7 @@ __device__ inline void gemm_pipeline_bf(f32x16 (&acc)[MI][2], f32x4& csum, const
 #endif
 }
 
-template <bool AK, bool BK, int MI, bool EDGE = false>
+template <bool AK, bool BK, int MI, bool EDGE = false, bool ANYPRE = false>
 __device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], f32x4& csum, const bool want_csum,
                                           const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                           int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB, BfStage<MI>& S) {
@@ -514,15 +518,15 @@ __device__ inline void gemm_accumulate_bf(f32x16 (&acc)[MI][2], f32x4& csum, con
     const bool both_fast = la.fast && lb.fast && kfull > kbeg;
     const bool both_full = la.full && lb.full;
     if (both_fast && both_full) {
-        gemm_pipeline_bf<AK, BK, MI, 1>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, S);
+        gemm_pipeline_bf<AK, BK, MI, 1, ANYPRE>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, S);
         if (kfull < kend)
-            gemm_pipeline_bf<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, S);
+            gemm_pipeline_bf<AK, BK, MI, 0, ANYPRE>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, S);
     } else if (EDGE && both_fast && !both_full) {
-        gemm_pipeline_bf<AK, BK, MI, 2>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, S);
+        gemm_pipeline_bf<AK, BK, MI, 2, ANYPRE>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kfull, vecA, vecB, S);
         if (kfull < kend)
-            gemm_pipeline_bf<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, S);
+            gemm_pipeline_bf<AK, BK, MI, 0, ANYPRE>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kfull, kend, vecA, vecB, S);
     } else {
-        gemm_pipeline_bf<AK, BK, MI, 0>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, S);
+        gemm_pipeline_bf<AK, BK, MI, 0, ANYPRE>(acc, csum, want_csum, la, lb, A, ra, B, rb, M, N, m0, n0, kbeg, kend, vecA, vecB, S);
     }
 }
 
@@ -535,13 +539,13 @@ template <int MI> struct TileMem<false, MI> {
 template <int MI> struct TileMem<true, MI> {
     BfStage<MI> st;
 };
-template <bool AK, bool BK, int MI, bool EDGE, bool BF>
+template <bool AK, bool BK, int MI, bool EDGE, bool BF, bool ANYPRE = false>
 __device__ inline void gemm_accumulate_any(f32x16 (&acc)[MI][2], float& csum, f32x4& csum4, const bool want_csum,
                                            const float* __restrict__ A, const RowMap& ra, const float* __restrict__ B, const RowMap& rb,
                                            int M, int N, int K, int m0, int n0, int kbeg, int kend, int vecA, int vecB,
                                            TileMem<BF, MI>& mem) {
     // csum (fp32 pipeline: one column, half the k rows per thread) / csum4 (bf16 pipeline: see bf_colsum)
-    if constexpr (BF) gemm_accumulate_bf<AK, BK, MI, EDGE>(acc, csum4, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.st);
+    if constexpr (BF) gemm_accumulate_bf<AK, BK, MI, EDGE, ANYPRE>(acc, csum4, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.st);
     else gemm_accumulate<AK, BK, MI, EDGE>(acc, csum, want_csum, A, ra, B, rb, M, N, K, m0, n0, kbeg, kend, vecA, vecB, mem.As, mem.Bs);
 }
 

@@ -353,6 +353,14 @@ def split4_supported(T, B, H, ndir):
     return v
 
 
+def split4_wanted(T, B, H, ndir):
+    """Policy on top of split4_supported: pre-split dgi / dghn pay where the 256-tile kernels (compile-time operand formats)
+    read them -- the cluster-recurrence shapes, 256 < H <= 512.  At H = 64 / 128 every reader is a 128-tile kernel whose
+    split4-capable instantiation carries run-time format flags in its k loop: measured neutral there, while keeping the flags
+    out of the fp32-operand instantiation is worth 2.4 % of the cfg-2 step."""
+    return H > 256 and split4_supported(T, B, H, ndir)
+
+
 def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     dev = gi.device
     y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
@@ -587,7 +595,7 @@ class GRULayerFmtFn(torch.autograd.Function):
             dyd = torch.empty_like(dyc)
             call('xps_dropout_f32', _ptr(dyc), _ptr(dyd), None, dyc.numel(), ctx.drop[0], ctx.drop[1], _stream())
             dy = dyd
-        fmt = 1 if split4_supported(T, B, H, ndir) else 0        # dgi / dghn only feed GEMMs: pre-split operands, same bits
+        fmt = 1 if split4_wanted(T, B, H, ndir) else 0           # dgi / dghn only feed GEMMs: pre-split operands, same bits
         dgi, dghn, _ = _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, False, ctx.drop if ctx.drop_fused else None,
                                      split4=bool(fmt))
         dev = x.device
