@@ -388,7 +388,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # rehearsal knob (1-GPU box): XPS_BENCH_FORCE_DP=1 (+ XPS_DP_SINGLE_RANK_COLLECTIVES=1) runs the data-parallel code path --
+    # SyncBN exchanges, flat-gradient all-reduces, hooks -- on a ONE-rank RCCL communicator: what the DP host path costs per step
+    force_dp = world == 1 and os.environ.get('XPS_BENCH_FORCE_DP') == '1'
+    if force_dp:
+        os.environ.setdefault('MASTER_PORT', '29577')
+    if world > 1 or force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -408,10 +413,10 @@ def main():
     explore = bool(args.hidden or args.channels)
     torch.manual_seed(1234)                      # identical initial weights on every rank
     model = build_model(c).to(dev)
-    if world > 1:
+    if world > 1 or force_dp:
         model.temporal_conv.process_group = dist.group.WORLD
         model.temporal_conv.global_batch = c['trials_per_gpu'] * world
-    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5, group=dist.group.WORLD if world > 1 else None)
+    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5, group=dist.group.WORLD if (world > 1 or force_dp) else None)
     X, y = make_data(rank, c)
     X, y = X.to(dev), y.to(dev)                  # inputs resident in HBM before the timed region
     torch.manual_seed(99)                        # the same teacher-forcing coins on every rank
