@@ -597,8 +597,9 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const float* __restric
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
     // fmt: bit 0 = A (and A2), bit 1 = B (and B2) are XPS_FMT_SPLIT4 operands; 16-deep stages: fmt == FMT (template), two
     // k loops in the kernel instead of eight (which spilled 300-400 registers)
-    big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K, (fmt & 1) != 0, (fmt & 2) != 0);
-    if (A2) big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2, (fmt & 1) != 0, (fmt & 2) != 0);
+    // (32-deep stages, opt-in: fp32 operands only -- the host never pairs them with split4 operands)
+    big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
+    if (A2) big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
     xps_big::big_store_c(acc, C, ldc, bias, m0, n0, accumulate);
 }
 
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* 
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
-    big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K, (fmt & 1) != 0, (fmt & 2) != 0);
+    big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
     xps_big::big_store_c(acc, pm.C[z], ldc, pm.bias[z], m0, n0, 0);
 }
 
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_tn_kernel(TnGroup g, float* _
     xps_big::big_zero(acc);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     big_accumulate<false, false, DEEP>(acc, csum, want_cs, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, kend,
-                                       (P.vecA & 2) != 0, (P.vecB & 2) != 0);
+                                       !DEEP && (P.vecA & 2) != 0, !DEEP && (P.vecB & 2) != 0);
     float* sub[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -783,7 +784,7 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
                                   big_prepare(gemm_big_kernel<AK, BK, true>, BIG_LDS32);
         if (ready) {
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN));
-            if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0)
+            if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0 && fmt == 0)
                 hipLaunchKernelGGL((gemm_big_kernel<AK, BK, true>), bgrid, dim3(xps_big::NTHR), BIG_LDS32, st,
                                    A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
             else if (fmt == 0)
@@ -931,7 +932,7 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
         static const bool ready = big_prepare(gemm_big_nt_multi_kernel<false>, BIG_LDS) && big_prepare(gemm_big_nt_multi_kernel<true>, BIG_LDS32);
         if (ready) {
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN) * nprob);
-            if (big_deep_allowed() && K % 32 == 0)
+            if (big_deep_allowed() && K % 32 == 0 && fmt == 0)
                 hipLaunchKernelGGL(gemm_big_nt_multi_kernel<true>, bgrid, dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, A, ra.ld, pm,
                                    rb.ld, rc.ld, N, K, nprob, fmt);
             else
@@ -1179,7 +1180,7 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
         // 1-5 % to the larger LDS block: 16-deep unless XPS_GEMM_BIG_DEEP_TN=1
         static const bool deep_tn = [] { const char* e = getenv("XPS_GEMM_BIG_DEEP_TN"); return e && e[0] == '1'; }();
         bool deep = big_deep_allowed() && deep_tn;
-        for (int i = 0; i < n; ++i) deep = deep && (!g.p[i].big || (g.p[i].kchunk % 32 == 0 && g.p[i].K % 32 == 0));
+        for (int i = 0; i < n; ++i) deep = deep && (!g.p[i].big || (g.p[i].kchunk % 32 == 0 && g.p[i].K % 32 == 0 && !((g.p[i].vecA | g.p[i].vecB) & 2)));
         if (deep)
             hipLaunchKernelGGL(gemm_big_tn_kernel<true>, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, g,
                                (float*)workspace);

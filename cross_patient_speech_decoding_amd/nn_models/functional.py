@@ -492,8 +492,10 @@ def split4_mode():
 
 def layer_output_split4_ok(T, B, H, ndir, drop_p):
     """A GRU layer whose dropped output is read by the NEXT layer's GEMMs only (input projection, dW_ih) can write it as
-    XPS_FMT_SPLIT4 groups in the dropout pass it runs anyway (shapes whose recurrence kernels do not fuse the dropout)."""
-    return bool(drop_p and drop_p > 0.0 and split4_mode() and (ndir * H) % 4 == 0 and not fused_dropout_supported(T, B, H, ndir))
+    XPS_FMT_SPLIT4 groups in the dropout pass it runs anyway (shapes whose recurrence kernels do not fuse the dropout; H > 256:
+    where the 256-tile kernels read it, see split4_wanted)."""
+    return bool(drop_p and drop_p > 0.0 and split4_mode() and H > 256 and (ndir * H) % 4 == 0
+                and not fused_dropout_supported(T, B, H, ndir))
 
 
 def _presplit_weights_ok(rows, In, H3):

@@ -51,7 +51,7 @@ typedef struct xps_rowmap {
 /* XPS_FMT_SPLIT4: every aligned group of four consecutive fp32 elements (16 bytes, along the contiguous index) holds the
  * bf16 split of its values instead: bytes 0-7 = hi[0..3] = bf16(x[0..3]), bytes 8-15 = lo[0..3] = bf16(x[j] - hi[j]) -- exactly
  * what the bf16x3 tile kernels compute while they stage an fp32 operand.  A producer that owns the split anyway (the BPTT
- * kernels, xps_dropout_f32 / xps_split4_f32 with split_out) writes it once; the GEMM entry points (nt / nn / nn2 / nt_multi /
+ * kernels through xps_gru_seq_bwd_split4_f32, a dropout pass or a weight matrix through xps_split4_f32) writes it once; the GEMM entry points (nt / nn / nn2 / nt_multi /
  * tn_grouped, bf16x3 mode only) then stage the operand without any conversion arithmetic and return the SAME BITS as for
  * the fp32 operand (a bias gradient folded from a split4 A operand sums hi + lo: within 2^-17 relative of the fp32 sum).
  * Needs 16-byte aligned operands, leading dimensions and the contiguous extent multiples of 4; else XPS_E_INVALID. */

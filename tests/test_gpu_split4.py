@@ -170,6 +170,8 @@ def test_requests_that_cannot_be_served_fail_loudly():
     lib().xps_set_gemm_precision(1)
     assert F.split4_supported(20, 2048, 128, 2) and F.split4_supported(20, 2048, 512, 2)
     assert not F.split4_supported(20, 2048, 200, 2)                         # generic kernels: fp32 outputs only
+    # policy: the BPTT kernels are asked for split outputs only where the 256-tile kernels read them
+    assert F.split4_wanted(20, 2048, 512, 2) and not F.split4_wanted(20, 2048, 128, 2)
 
 
 @pytest.mark.parametrize('T,B,H,ndir,drop', [(6, 300, 128, 2, None), (5, 64, 64, 1, None), (6, 300, 128, 2, (0.3, 77)),
