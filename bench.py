@@ -362,6 +362,34 @@ def fp32_record(c, dev, steps=20, warm=30):
             'steps': steps, 'warmup': warm}
 
 
+def _set_affinity_all_threads(cores):
+    """sched_setaffinity for every thread of this process (threads keep the mask they were created with)."""
+    try:
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                os.sched_setaffinity(int(tid), cores)
+            except OSError:
+                pass
+    except OSError:
+        pass
+
+
+def pin_host_threads(local_rank):
+    """One trainer process per GPU, pinned to a few cores of its own (XPS_BENCH_PIN_CORES, default 4; 0 = leave the scheduler
+    alone).  The enqueue path of a step needs ~1.0 ms of host time against ~1.05 ms of GPU time, so a main or autograd thread
+    that migrates across a 256-core host shows up in a 20-step window: tools/jitter.py, 150 windows in one process:
+    unpinned p90 / p97 / max = 1.124 / 1.347 / 1.638 ms per step (median 1.082), pinned to 2-4 cores 1.08 / 1.09 / 1.19-1.33.
+    Returns the original mask (restored for the CPU-baseline leg, which wants all cores)."""
+    full = os.sched_getaffinity(0)
+    n = int(os.environ.get('XPS_BENCH_PIN_CORES', '4'))
+    if n > 0:
+        cores = sorted(full)
+        sel = cores[local_rank * n:(local_rank + 1) * n]
+        if len(sel) == n:
+            _set_affinity_all_threads(set(sel))
+    return full
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -382,6 +410,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
+    full_affinity = pin_host_threads(local_rank)
     # rehearsal knobs (1-GPU box): XPS_BENCH_BACKEND=gloo XPS_BENCH_ONE_DEVICE=1 put every rank on cuda:0
     backend = os.environ.get('XPS_BENCH_BACKEND', 'nccl')
     if os.environ.get('XPS_BENCH_ONE_DEVICE'):
@@ -507,6 +536,7 @@ def main():
             out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:
             try:
+                _set_affinity_all_threads(full_affinity)        # the CPU oracle gets every core of the host share
                 out['cpu_baseline'] = cpu_baseline(c)
             except Exception as e:                                           # noqa: BLE001
                 out['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
