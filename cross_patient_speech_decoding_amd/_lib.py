@@ -165,6 +165,15 @@ def check(rc, what=''):
         raise XpsError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
 
 
+_fns = {}
+
+
 def call(name, *args):
-    """Call an int-returning entry point and raise on a non-zero code."""
-    check(getattr(lib(), name)(*args), name)
+    """Call an int-returning entry point and raise on a non-zero code.  (The bound functions are cached: a training step makes
+    ~45 of these calls and the host path is as long as the GPU's.)"""
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    rc = fn(*args)
+    if rc:
+        check(rc, name)
