@@ -14,7 +14,7 @@ def prof(fn):
         finally:
             pr.disable()
     return staticmethod(w)
-for cls in [XF.GRULayerFn, XF.TemporalConvFn, XF.DecoderFn, XF.LinearFn, XF.CrossEntropyFn, XF.DropoutFn]:
+for cls in [XF.GRULayerFmtFn, XF.TemporalConvFn, XF.DecoderFn, XF.LinearFn, XF.CrossEntropyFn, XF.DropoutFn]:
     cls.backward = prof(cls.backward)
 c = bench.CFG
 torch.manual_seed(1234)

@@ -27,4 +27,4 @@ print(f'host enqueue per step (B=256, GPU not limiting) {t_enq / n * 1e3:.3f} ms
 pr = cProfile.Profile(); pr.enable()
 for _ in range(n): step()
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(28)
+st = pstats.Stats(pr); st.sort_stats(os.environ.get('SORT', 'tottime')).print_stats(int(os.environ.get('TOP', '28')))
