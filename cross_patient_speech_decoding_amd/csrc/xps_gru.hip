@@ -1225,8 +1225,11 @@ inline bool use_step_path() {
 
 }  // namespace
 
+// The cluster kernels address y_ext, saved and dgi through raw buffer descriptors (32-bit sizes and offsets): the LARGEST of
+// them, saved = ndir * T * B * 4H floats (y_ext is (T + 2) * B * ndir * H, dgi ndir * T * B * 3H), must stay below 4 GiB;
+// longer sequences take the per-step path.
 static bool cluster_shape_ok(int T, int B, int H, int ndir) {
-    return xps_internal_gru_cluster_usable(B, H, ndir) && (long long)(T + 2) * B * ndir * H * 4 < (1ll << 32);
+    return xps_internal_gru_cluster_usable(B, H, ndir) && (long long)ndir * (T + 2) * B * 4 * H * 4 < (1ll << 32);
 }
 
 extern "C" size_t xps_gru_seq_fwd_f32_workspace(int T, int B, int H, int ndir) {

@@ -90,7 +90,7 @@ __device__ inline float cl_tanh(float x) { return 2.0f * cl_sigmoid(2.0f * x) - 
 // one wave polls the CS flags of a round until every member has published `need`; bounded (3 s).  Slow path only (the
 // look-ahead poll found the round unpublished): status[1] counts such waits, status[2] sums and status[3] keeps the longest
 // of them in 10 ns ticks (diagnostics read by tools/bench_gru.py; status[0] != 0 means a wait gave up).
-__device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int lane, unsigned first, unsigned* status) {
+__device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int lane, unsigned first, unsigned* status, unsigned* sticky) {
     unsigned v = first;
     if (__all(v >= need)) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
@@ -104,7 +104,10 @@ __device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int
     }
     if (lane == 0) {
         const unsigned dt = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);
-        if (!ok) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(status + 2, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_max(status + 3, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -115,7 +118,7 @@ __device__ inline void cl_wait(const unsigned* flags, unsigned need, int cs, int
 // its XCC id, one wave collects the CS ids.  Same XCD: the members share an L2, so exchange stores may stay write-back
 // (plain) and the sc1 loads (which bypass L1 only) hit that L2 instead of going to the memory side.  Otherwise every
 // exchange store is write-through (sc1).  All members read the same table, so the whole cluster takes the same decision.
-__device__ inline bool cl_same_xcd(unsigned* tab, int member, int cs, int lane, bool leader, unsigned* status, unsigned* lds_word) {
+__device__ inline bool cl_same_xcd(unsigned* tab, int member, int cs, int lane, bool leader, unsigned* status, unsigned* sticky, unsigned* lds_word) {
     if (leader) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
@@ -131,7 +134,10 @@ __device__ inline bool cl_same_xcd(unsigned* tab, int member, int cs, int lane, 
             __builtin_amdgcn_s_sleep(2);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) break;
         }
-        if (!ok && lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok && lane == 0) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const bool same = ok && __all(v == id);
         if (lane == 0) {
             *lds_word = same ? 1u : 0u;
@@ -252,6 +258,7 @@ struct ClFwd {
     unsigned* flags;       // [cluster][NR][16]
     unsigned* xcc;         // [cluster][16]  XCC id + 1 of every member (cl_same_xcd)
     unsigned* status;
+    unsigned* sticky;      // per-device word that outlives the workspace (xps_gru_set_status_word) or NULL
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
     int s_begin, s_end, handoff;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     if (tid < 4) consumed[tid] = 0u;
 
     // one step per launch: the kernel boundary publishes everything; persistent: write-back stores only inside one XCD
-    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, p.sticky, reinterpret_cast<unsigned*>(smem));
 
     // gate wave 4 + h moves pieces [16 h, 16 h + 16) of a round (trials 8 h .. 8 h + 7 of the 32) in four groups of four
     const int mvw = wave & 3;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         CL_FENCE();
         CL_STAMP(sb3)
         cl_wait_vmcnt(younger);                             // exchange rows complete; outputs / later inputs stay in flight
-        if (do_poll) cl_wait(myflags + r_n2 * 16, (unsigned)s_n2, p.CS, lane, fl, p.status);
+        if (do_poll) cl_wait(myflags + r_n2 * 16, (unsigned)s_n2, p.CS, lane, fl, p.status, p.sticky);
         CL_STAMP(sb0)
         __syncthreads();
         CL_STAMP(sb1)
@@ -637,6 +644,7 @@ struct ClBwd {
     unsigned* flags;
     unsigned* xcc;
     unsigned* status;
+    unsigned* sticky;
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
     int ps_begin, ps_end, ps_total, handoff;
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     const int m_base = blk * p.Mc;
     const int NQ = 3 * NR;                              // sub-iterations (round, gate segment) per processing step
     unsigned* myflags = p.flags + (long long)cm.cluster * NR * 16;
-    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, reinterpret_cast<unsigned*>(smem));
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, p.CS, lane, wave == 4, p.status, p.sticky, reinterpret_cast<unsigned*>(smem));
 
     // gate waves: unit tile, trial tile, units, buffers
     const int hw = wave >= 4 ? wave - 4 : 0;
@@ -815,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         // the first two sub-iterations (round 0, segments 0 and 1) are loaded without a look-ahead poll
         unsigned f0 = 0xffffffffu;
         if (lane < p.CS) f0 = __hip_atomic_load(myflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cl_wait(myflags, (unsigned)ps0, p.CS, lane, f0, p.status);
+        cl_wait(myflags, (unsigned)ps0, p.CS, lane, f0, p.status, p.sticky);
     }
     __syncthreads();
     if (wave < 4) {
@@ -972,7 +980,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             }
             if (g == 2) { pend_ps = ps; pend_r = r; }
             CL_STAMP(sb3)
-            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status);
+            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status, p.sticky);
             if (BF && g != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
             CL_STAMP(sb0)
             __syncthreads();
@@ -999,14 +1007,32 @@ struct ClPlan {
     size_t flags_bytes, xbuf_fwd, xbuf_bwd, keep_bytes;
 };
 
+// Per-device facts, looked up for the CURRENT device of the calling thread (one process may drive several GPUs): the CU
+// count, how many workgroups of each cluster kernel the device holds at once (occupancy query x CUs: the persistent form
+// spins across workgroups, so its whole grid must be co-resident), and the caller's sticky status word.
+struct ClDev {
+    int cus = -1;
+    int resident[2][2] = {{-1, -1}, {-1, -1}};        // [fwd / bwd][fp32 / bf16x3]
+    unsigned* sticky = nullptr;
+};
+constexpr int CL_MAX_DEV = 64;
+ClDev g_cldev[CL_MAX_DEV];
+
+int cl_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CL_MAX_DEV) return -1;
+    return dev;
+}
+
 int cl_num_cus() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return cus;
-    }();
-    return n;
+    const int dev = cl_device();
+    if (dev < 0) return 0;
+    if (g_cldev[dev].cus < 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        g_cldev[dev].cus = cus;
+    }
+    return g_cldev[dev].cus;
 }
 
 // mode: 0 = off (per-step GEMM kernels of xps_gru.hip), 1 = cluster kernels one step per launch, 2 = persistent (default)
@@ -1062,7 +1088,35 @@ bool cl_set_lds(K kernel, int bytes) {
 
 inline bool cl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// workgroups of `kernel` (512 threads, `lds` bytes) the current device holds at once; cached per device and kernel kind
+template <typename K>
+int cl_resident(K kernel, int lds, int bwd, int bf) {
+    const int dev = cl_device();
+    if (dev < 0) return 0;
+    int& slot = g_cldev[dev].resident[bwd][bf];
+    if (slot < 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 512, (size_t)lds) != hipSuccess) per_cu = 0;
+        slot = per_cu * cl_num_cus();
+    }
+    return slot;
+}
+
+unsigned* cl_sticky() {
+    const int dev = cl_device();
+    return dev < 0 ? nullptr : g_cldev[dev].sticky;
+}
+
 }  // namespace
+
+// A device word that outlives every workspace: a hand-off that gave up stores 1 there as well (NULL: none).  Per device;
+// the caller owns the memory, zeroes it, and reads it where it synchronises anyway.
+extern "C" int xps_gru_set_status_word(unsigned* device_word) {
+    const int dev = cl_device();
+    if (dev < 0) { xps_set_error("xps_gru_set_status_word: no current device"); return XPS_E_HIP; }
+    g_cldev[dev].sticky = device_word;
+    return XPS_OK;
+}
 
 // ---- internal interface used by xps_gru.hip's entry points ----
 bool xps_internal_gru_cluster_usable(int B, int H, int ndir) { return cl_plan(B, H, ndir).ok; }
@@ -1113,9 +1167,11 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
         if (bf) hipLaunchKernelGGL(gru_cluster_init_kernel<true>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP);
         else hipLaunchKernelGGL(gru_cluster_init_kernel<false>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP);
     }
-    const bool persistent = cl_mode() == 2 && pl.grid <= cl_num_cus();
+    p.sticky = cl_sticky();
     auto launch = [&](auto kernel, int lds) -> bool {
         if (!cl_set_lds(kernel, lds)) return false;
+        // the persistent form spins across workgroups: only when the device holds the whole grid at once
+        const bool persistent = cl_mode() == 2 && pl.grid <= cl_resident(kernel, lds, 0, bf ? 1 : 0);
         if (persistent) {
             p.s_begin = 0; p.s_end = T; p.handoff = 1;
             hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
@@ -1166,9 +1222,10 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     }
     const int ps_total = T + (dh0 ? 1 : 0);
     p.ps_total = ps_total;
-    const bool persistent = cl_mode() == 2 && pl.grid <= cl_num_cus();
+    p.sticky = cl_sticky();
     auto launch = [&](auto kernel, int lds) -> bool {
         if (!cl_set_lds(kernel, lds)) return false;
+        const bool persistent = cl_mode() == 2 && pl.grid <= cl_resident(kernel, lds, 1, bf ? 1 : 0);
         if (persistent) {
             p.ps_begin = 0; p.ps_end = ps_total; p.handoff = 1;
             hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);

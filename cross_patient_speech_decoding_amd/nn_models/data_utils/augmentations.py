@@ -2,7 +2,11 @@
 per call, in the same order) as the reference's nn_models/data_utils/augmentations.py (:13,32,51,65,79), computed by the HIP
 kernels of csrc/xps_augment.hip.  A tensor that already lives on the GPU stays there (augmentation per epoch on the device);
 a host tensor (what DataModule.setup() holds, as in the reference) is uploaded, augmented and returned on the host.  There is
-no CPU fallback: without the GPU these raise."""
+no CPU fallback: without the GPU these raise (deliberately: the product path never computes on the host).
+
+Precision: the kernels compute in float32 -- the dtype of every tensor the DataModules hold (the reference's `torch.Tensor(...)`
+casts, datamodules.py:574).  A float64 input is rounded to float32, augmented and cast back (the reference would keep float64
+arithmetic there); the goldens in tests/golden/augmentations.npz are float32."""
 import numpy as np
 import torch
 

@@ -289,30 +289,32 @@ def _gru_ws_bytes(fn, T, B, H, ndir):
     return n
 
 
-# The cluster-persistent recurrence (128 < H <= 512) bounds every in-kernel wait; a wait that gave up sets a status word in
-# its workspace.  The words of the launches since the last check are kept (4-byte views) and read by check_gru_status(),
-# which the trainer calls where it synchronises anyway (when it reads the loss).
-_gru_status_words = []
+# The cluster-persistent recurrence (256 < H <= 512) bounds every in-kernel wait; a wait that gave up stores 1 into ONE small
+# persistent word per device (xps_gru_set_status_word).  Nothing is read during a step: check_gru_status() is called where the
+# host synchronises anyway (the Trainer: when it reads the epoch's loss, and at the end of fit / validate / test / predict).
+_gru_status_word = {}
 
 
-def _note_gru_status(ws, T, B, H, ndir):
-    off = lib().xps_gru_seq_status_offset(T, B, H, ndir)
-    if off >= 0:
-        if len(_gru_status_words) >= 64:
-            check_gru_status()
-        _gru_status_words.append(ws[off:off + 4])
+def _gru_status_register(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _gru_status_word.get(idx)
+    if w is None:
+        w = _gru_status_word[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device('cuda', idx))
+        with torch.cuda.device(idx):
+            call('xps_gru_set_status_word', w.data_ptr())
+    return w
 
 
 def check_gru_status():
-    """Synchronising check of the hand-off status words of the recurrence launches since the last call."""
-    if not _gru_status_words:
-        return
-    words = torch.cat(_gru_status_words).view(torch.int32)
-    _gru_status_words.clear()
-    if int(words.abs().sum().item()) != 0:
-        raise RuntimeError('xps_gru_seq: an in-kernel hand-off of the cluster-persistent GRU recurrence timed out (the GPU is '
-                           'shared with another persistent launch?); results are invalid.  XPS_GRU_CLUSTER=steps avoids '
-                           'in-kernel hand-offs')
+    """Synchronising check of the per-device hand-off status words (set by a cluster-recurrence launch whose in-kernel wait
+    timed out since the last call)."""
+    bad = [idx for idx, w in _gru_status_word.items() if int(w.item()) != 0]
+    for idx in bad:
+        _gru_status_word[idx].zero_()
+    if bad:
+        raise RuntimeError(f'xps_gru_seq: an in-kernel hand-off of the cluster-persistent GRU recurrence timed out on device(s) {bad} '
+                           '(the GPU is shared with another persistent launch?); the results since the last check are invalid.  '
+                           'XPS_GRU_CLUSTER=steps runs the same kernels without in-kernel hand-offs')
 
 
 def set_gru_cluster_mode(name):
@@ -367,6 +369,8 @@ def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     saved = torch.empty(ndir, T, B, 4 * H, dtype=_f32, device=dev) if save else None
     nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
+    if nbytes > 16:
+        _gru_status_register(dev)
     if drop is not None:
         # inter-layer dropout fused into the recurrence kernel: a second output y_drop = y * keep / (1 - p)
         y_drop = torch.empty(T, B, ndir * H, dtype=_f32, device=dev)
@@ -375,7 +379,6 @@ def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
         return y_ext, saved, y_drop
     call('xps_gru_seq_fwd_f32', _ptr(gi), _ptr_array(w_hh), _ptr_array(b_hh), _ptr(h0), _ptr(y_ext),
          _ptr(saved), T, B, H, ndir, _ptr(ws), nbytes, _stream())
-    _note_gru_status(ws, T, B, H, ndir)
     return y_ext, saved
 
 
@@ -400,12 +403,12 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=Non
     dh0 = torch.empty(ndir, B, H, dtype=_f32, device=dev) if need_dh0 else None
     nbytes = _gru_ws_bytes('xps_gru_seq_bwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
+    _gru_status_register(dev)
     if split4:
         fused = drop is not None and dy is not None
         call('xps_gru_seq_bwd_split4_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
              _ptr(dghn), _ptr(dh0), T, B, H, ndir, float(drop[0]) if fused else 0.0, int(drop[1]) if fused else 0, _ptr(ws), nbytes,
              _stream())
-        _note_gru_status(ws, T, B, H, ndir)
         return dgi, dghn, dh0
     if drop is not None and dy is not None:
         # dy is the gradient w.r.t. the dropped output of the forward kernel: the decisions are re-made while it is loaded
@@ -414,7 +417,6 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=Non
         return dgi, dghn, dh0
     call('xps_gru_seq_bwd_f32', _ptr(dy), _ptr(dhn), _ptr(y_ext), _ptr(saved), _ptr_array(w_hh), _ptr_array(w_t), _ptr(dgi),
          _ptr(dghn), _ptr(dh0), T, B, H, ndir, _ptr(ws), nbytes, _stream())
-    _note_gru_status(ws, T, B, H, ndir)
     return dgi, dghn, dh0
 
 
@@ -663,28 +665,28 @@ class GRULayerFn(torch.autograd.Function):
 # TemporalConv: Conv1d -> BatchNorm1d -> [ReLU] -> Dropout                      #
 # --------------------------------------------------------------------------- #
 POST_SYNCBN_HOOKS = []
-# World size from which the data-parallel code paths (SyncBN exchanges, gradient all-reduce) run.  2 in production;
-# XPS_DP_SINGLE_RANK_COLLECTIVES=1 makes it 1, so that a ONE-rank RCCL communicator executes every collective of the path on a
-# one-GPU box (tests/test_gpu_training.py: ReduceOp.AVG, the async tail all-reduce issued from the autograd thread, device_id
-# init) -- averaging over one rank must reproduce the plain step.
-MIN_DP_WORLD = 1 if os.environ.get('XPS_DP_SINGLE_RANK_COLLECTIVES') == '1' else 2
-
-
-def _group_world(group):
-    """> 1 when the data-parallel paths are to run for this group (see MIN_DP_WORLD)."""
+def _dp_world(group):
+    """World size of `group` when torch.distributed is up, else 1.  The data-parallel paths (SyncBN exchanges, gradient
+    all-reduce) run iff _dp_enabled(group)."""
     import torch.distributed as dist
     if group is not None and dist.is_available() and dist.is_initialized():
-        w = dist.get_world_size(group)
-        return 2 if (w == 1 and MIN_DP_WORLD == 1) else w
+        return dist.get_world_size(group)
     return 1
+
+
+def _dp_enabled(group):
+    """Production rule: more than one rank.  (The one-rank RCCL rehearsals -- tests/dp_worker.py --device nccl1,
+    bench.py with XPS_BENCH_FORCE_DP=1 -- replace THIS function from the outside to exercise the same code on a one-GPU box.)"""
+    return _dp_world(group) > 1
 
 
 def _dist_sum_(t, group):
-    import torch.distributed as dist
-    if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_DP_WORLD:
+    """In-place sum over the ranks of `group` when the data-parallel paths are on; returns whether it ran."""
+    if _dp_enabled(group):
+        import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return max(dist.get_world_size(group), 2) if MIN_DP_WORLD == 1 else dist.get_world_size(group)
-    return 1
+        return True
+    return False
 
 
 def _global_rows(rows, group, device, global_trials, Tp):
@@ -724,9 +726,9 @@ class TemporalConvFn(torch.autograd.Function):
         if training:
             stats = torch.empty(2 * F, dtype=_f32, device=x.device)
             colsum(y, rows, F, out=stats[:F], out_sq=stats[F:])
-            world = _dist_sum_(stats, group)
+            synced = _dist_sum_(stats, group)
             count = float(rows)
-            if world > 1:
+            if synced:
                 count = _global_rows(rows, group, x.device, global_trials, Tp)
             mean = torch.empty(F, dtype=_f32, device=x.device)
             rstd = torch.empty(F, dtype=_f32, device=x.device)
@@ -758,15 +760,15 @@ class TemporalConvFn(torch.autograd.Function):
         g_beta, acc_beta, _ = _grad_target(ctx.bn_params[1], (F,), dev)
         g_gamma, acc_gamma, _ = _grad_target(ctx.bn_params[0], (F,), dev)
         direct_bn = acc_beta and acc_gamma
-        world = _group_world(group)
+        dp = _dp_enabled(group)
         call('xps_bn_bwd_reduce_f32', _ptr(dout), _ptr(out), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(drop_mask),
              drop_scale, int(relu), _ptr(sums), _ptr(g_beta) if direct_bn else None, _ptr(g_gamma) if direct_bn else None,
              rows, F, _ptr(ws), nbytes, _stream())
         dbeta = dgamma = None
         if not direct_bn:
-            local = sums.clone() if world > 1 else sums
+            local = sums.clone() if dp else sums
             dbeta, dgamma = local[:F], local[F:]
-        if world > 1:                           # SyncBN: the dy formula needs the global sums
+        if dp:                                  # SyncBN: the dy formula needs the global sums
             _dist_sum_(sums, group)
             # every gradient downstream of this layer is enqueued by now: a data-parallel optimiser may start
             # reducing them (AFTER the statistics exchange above, so that it never queues behind a large one)
@@ -922,6 +924,7 @@ class DecoderWideFn(torch.autograd.Function):
         saved = torch.empty(1, L, B, 4 * H, dtype=_f32, device=dev) if save else None
         gi = torch.empty(B, 3 * H, dtype=_f32, device=dev)
         nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', 1, B, H, 1)
+        _gru_status_register(dev)
         w_arr, b_arr = _ptr_array([w_hh_c]), _ptr_array([b_hh_c])
         rc = rowmap(C)
         fused_select = C <= 16                          # logits + next token + its table row in one launch
@@ -933,7 +936,6 @@ class DecoderWideFn(torch.autograd.Function):
             # by the next step)
             call('xps_gru_seq_fwd_f32', _ptr(gi), w_arr, b_arr, _ptr(h0c if s == 0 else hs[s]), _ptr(hs[s:]),
                  _ptr(saved[0, s]) if save else None, 1, B, H, 1, _ptr(ws), nbytes, _stream())
-            _note_gru_status(ws, 1, B, H, 1)
             tstride = teacher.stride(0) if teacher is not None else 0
             if fused_select:
                 last = s + 1 == L

@@ -74,9 +74,7 @@ class FlatAdamW:
         self._split = None
         self._early = None
         self._comm_stream = None
-        world, _ = _world(group)
-        # the data-parallel paths run from world size XF.MIN_DP_WORLD on (2; 1 only in the single-rank RCCL rehearsal test)
-        self._dp = group is not None and dist.is_available() and dist.is_initialized() and world >= XF.MIN_DP_WORLD
+        self._dp = XF._dp_enabled(group)        # more than one rank (the one-rank RCCL rehearsals patch XF._dp_enabled)
         # RCCL averages in the collective (no extra pass over the buffer); gloo (CPU tests) sums, then one scale
         self._avg = self._dp and dist.get_backend(group) == 'nccl'
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -135,7 +133,7 @@ class FlatAdamW:
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 p.grad = view
-        if self._dp or world > 1:
+        if self._dp:
             if self._early is not None:                    # the tail went out during backward: only the head is left
                 self._early.wait()                         # (current stream waits for the collective)
                 self._early = None
@@ -245,8 +243,11 @@ class Trainer:
         else:
             opt = cfg
         g = opt.param_groups[0]
+        group = self.group
+        if group is None and _world()[0] > 1:
+            group = dist.group.WORLD                      # one process per GPU: the default group is the data-parallel group
         self.optimizer = FlatAdamW(model, lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'],
-                                   max_norm=self.gradient_clip_val, group=self.group)
+                                   max_norm=self.gradient_clip_val, group=group)
         self.scheduler = None
         if sched is not None:
             sch = sched
@@ -281,7 +282,9 @@ class Trainer:
                 for k, v in model._xps_logged.items():
                     sums[k] = sums.get(k, 0.0) + float(v) * n
                 count += n
-        return self._reduce_metrics(sums, count)
+        out = self._reduce_metrics(sums, count)
+        XF.check_gru_status()
+        return out
 
     # ---- public API ---------------------------------------------------------------------------
     def fit(self, model, train_dataloaders=None, val_dataloaders=None):
@@ -317,6 +320,7 @@ class Trainer:
                     sums[k] = sums.get(k, 0.0) + float(v) * n
                 count += n
             metrics = self._reduce_metrics(sums, count)
+            XF.check_gru_status()                     # (the loss was just read: the device is synchronised anyway)
             if val_dataloaders is not None:
                 metrics.update(self._run_eval(model, val_dataloaders, 'val'))
             metrics['lr'] = self.optimizer.lr
@@ -326,6 +330,8 @@ class Trainer:
                     cb.update(metrics, model)
             if self.scheduler is not None:
                 self.scheduler.step()
+        torch.cuda.synchronize(dev)
+        XF.check_gru_status()
         return self
 
     def test(self, model, dataloaders=None, ckpt_path=None):
@@ -339,6 +345,20 @@ class Trainer:
         metrics = self._run_eval(model, dataloaders, 'test')
         self.logged_metrics.update(metrics)
         return [metrics]
+
+    def predict(self, model, dataloaders=None):
+        """Lightning's predict loop: list of ``predict_step`` outputs (this rank's shard of every batch)."""
+        world, rank = _world(self.group)
+        dev = self._device()
+        model.to(dev).eval()
+        outs = []
+        with torch.no_grad():
+            for bi, batch in enumerate(dataloaders):
+                batch = tuple(_shard(t, rank, world).to(dev) for t in batch)
+                outs.append(model.predict_step(batch, bi))
+        torch.cuda.synchronize(dev)
+        XF.check_gru_status()
+        return outs
 
     def validate(self, model, dataloaders=None):
         metrics = self._run_eval(model, dataloaders, 'val')

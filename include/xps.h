@@ -19,7 +19,8 @@
  *     thread-local message.  No C++ exception crosses the boundary;
  *   - re-entrant.  Global state: exactly two process-wide mode switches, both plain ints read at call time --
  *     xps_set_gemm_precision (product precision of the matrix kernels) and xps_set_gru_cluster_mode (launch form of the
- *     H > 256 recurrence) -- plus the immutable per-process cache of the device's CU count; nothing else outlives a call.
+ *     H > 256 recurrence) -- plus a per-device cache of immutable device facts (CU count, resident workgroups of the cluster kernels) and the
+ *     caller's per-device status word (xps_gru_set_status_word); nothing else outlives a call.
  *
  * Matrices are row-major float32 unless stated.  A "row map" (rpg, gs, ld) addresses
  * row i of a matrix at element offset  (i / rpg) * gs + (i % rpg) * ld ; an ordinary
@@ -150,6 +151,11 @@ int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, 
  * status word); the caller checks it whenever it synchronises anyway.                                                    */
 size_t xps_gru_seq_fwd_f32_workspace(int T, int B, int H, int ndir);
 long long xps_gru_seq_status_offset(int T, int B, int H, int ndir);
+/* A caller-owned, zero-initialised 32-bit DEVICE word for the current device (NULL: none) that outlives the workspaces: a
+ * hand-off that timed out stores 1 there as well, so a trainer checks ONE word per device where it reads the loss instead of
+ * keeping every launch's workspace alive.  The persistent form is only launched when the occupancy query says the device
+ * holds the whole grid at once; otherwise (and always with mode 1) the same kernels run one step per launch.               */
+int xps_gru_set_status_word(unsigned* device_word);
 int xps_set_gru_cluster_mode(int mode);
 int xps_get_gru_cluster_mode(void);
 int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,

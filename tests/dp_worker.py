@@ -124,15 +124,15 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     if a.device == 'nccl1':
-        # ONE rank on a real RCCL communicator (XPS_DP_SINGLE_RANK_COLLECTIVES=1 makes the data-parallel paths run at world
-        # size 1): ReduceOp.AVG, device_id= init, SyncBN exchanges and the async tail all-reduce issued from the autograd
-        # thread all execute on RCCL; averaging over one rank must give the plain step bit for bit
-        assert os.environ.get('XPS_DP_SINGLE_RANK_COLLECTIVES') == '1'
+        # ONE rank on a real RCCL communicator.  The product runs its data-parallel paths for more than one rank only
+        # (functional._dp_enabled); THIS test replaces that rule from the outside so that ReduceOp.AVG, device_id= init, the
+        # SyncBN exchanges and the async tail all-reduce issued from the autograd thread all execute on RCCL on a one-GPU box;
+        # averaging over one rank must give the plain step bit for bit
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
         X, y = data()
         from cross_patient_speech_decoding_amd.nn_models import functional as XF
-        assert XF.MIN_DP_WORLD == 1
+        XF._dp_enabled = lambda group: group is not None
         calls = []
         real = dist.all_reduce
         def spy(t, *args, **kw):
@@ -173,8 +173,16 @@ def main():
         assert eg < 2e-4, f'gradient mismatch {eg}'
         assert abs(n1 - n2) < 2e-4 * n1, (n1, n2)
         assert (rv1 - rv2).abs().max().item() < 1e-5
-        # conv bias excluded from the weight check: zero-gradient noise through Adam (see test_gpu_seq2seq)
-        assert (p1 - p2).abs().max().item() < 2.5e-3
+        # updated weights: Adam's first step moves a weight by lr * g / (|g| + eps) -- for |g| >> eps that is lr * sign(g), blind
+        # to everything but the sign, and for |g| ~ eps (1e-8) it amplifies rounding noise to +-lr.  So (1) elements whose gradient
+        # is above the noise floor (1e-3 of the flat buffer's largest; the two runs differ by < 2e-4 of it) must have the same
+        # sign and hence the same update to 1e-5 * lr ... and (2) every element must have moved by at most lr (+ weight decay)
+        lr = 1e-3
+        d = (p1 - p2).abs()
+        big = g1.abs() > 1e-3 * g1.abs().max()
+        assert big.float().mean().item() > 0.05, 'too few elements above the noise floor: the check would be empty'
+        assert d[big].max().item() <= 1e-5, f'updated weights differ by {d[big].max().item()} on elements above the noise floor'
+        assert d.max().item() <= 2.0 * lr * 1.001, d.max().item()
     print('DP_OK')
 
 

@@ -129,11 +129,11 @@ def test_data_parallel_two_ranks_equal_single_process():
 
 
 def test_rccl_collectives_execute_on_a_one_rank_communicator():
-    """A one-GPU box cannot hold two RCCL ranks, but it can hold ONE: with XPS_DP_SINGLE_RANK_COLLECTIVES=1 the data-parallel
-    paths run at world size 1, so `init_process_group('nccl', device_id=)`, the SyncBN exchanges, `ReduceOp.AVG` on the flat
+    """A one-GPU box cannot hold two RCCL ranks, but it can hold ONE: the worker replaces functional._dp_enabled (test side: the
+    product rule is "more than one rank") so that the data-parallel paths run at world size 1, and `init_process_group('nccl', device_id=)`, the SyncBN exchanges, `ReduceOp.AVG` on the flat
     gradient and the async tail all-reduce issued from the autograd thread all EXECUTE on RCCL (tests/dp_worker.py --device nccl1
     checks that they were issued and that the step equals the plain step bit for bit).  The 2-rank test below needs 2 GPUs."""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29549', XPS_DP_SINGLE_RANK_COLLECTIVES='1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29549')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', '1', '--device', 'nccl1'], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'DP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
