@@ -182,3 +182,22 @@ def test_persistent_under_concurrent_load(cluster_mode):
         side.synchronize()
         for p, q in zip(out, ref):
             assert torch.equal(p, q), f'repeat {rep}'
+
+
+def test_cluster_path_is_bounded_by_its_largest_32_bit_buffer():
+    """The cluster kernels address y_ext, saved and dgi through raw buffer descriptors (32-bit sizes / offsets).  The shape
+    guard must bound the LARGEST of them (saved: ndir * T * B * 4H floats), not y_ext alone: at B = 2048, H = 512, both
+    directions, that is T <= 125; longer sequences must select the per-step path (status offset -1, 16-byte forward
+    workspace) instead of wrapping store offsets (host logic only: no launch)."""
+    from cross_patient_speech_decoding_amd._lib import lib
+    L = lib()
+    B, H = 2048, 512
+    assert L.xps_gru_seq_status_offset(20, B, H, 2) >= 0
+    for T in (120, 125):
+        assert 2 * (T + 2) * B * 4 * H * 4 < 2 ** 32 and L.xps_gru_seq_status_offset(T, B, H, 2) >= 0, T
+    for T in (126, 128, 200, 511):
+        assert 2 * (T + 2) * B * 4 * H * 4 >= 2 ** 32
+        assert L.xps_gru_seq_status_offset(T, B, H, 2) == -1, T
+        assert L.xps_gru_seq_fwd_f32_workspace(T, B, H, 2) == 16
+        assert L.xps_gru_seq_bwd_split4_supported(T, B, H, 2) == 0
+    assert L.xps_gru_seq_status_offset(250, B, H, 1) >= 0 and L.xps_gru_seq_status_offset(254, B, H, 1) == -1

@@ -212,19 +212,21 @@ def test_fused_decoder_equals_composed_path_and_oracle(H, B):
     assert (results[True][0] - results[False][0]).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize('H', [512, 500])
-def test_north_star_model_shape_vs_oracle(H, gemm_precision):
+@pytest.mark.parametrize('H,B', [(512, 256), (500, 256), (512, 2048)])
+def test_north_star_model_shape_vs_oracle(H, B, gemm_precision):
     """configs[3] model shape (aligned d = 30 input channels, F = 100, 2-layer bidirectional GRU encoder with H = 512 --
     and H = 500, the reference script's default, scripts/train_seq2seq.py:132 / nn_models/models.py:661-663 -- 1-layer
-    decoder), B = 256 trials: eval logits <= 1e-4 with identical argmax, then ONE full training step (teacher forcing
-    mixed, no dropout): logits, loss, every parameter gradient, clipped gradient norm and the AdamW-updated weights
-    against the CPU oracle.  The encoder runs the cluster-persistent recurrence (csrc/xps_gru_cluster.hip)."""
+    decoder), B = 256 trials and B = 2048 = THE BENCH SHARD ITSELF (the per-GPU batch of `bench.py`'s headline: other
+    cluster plans / round counts than B = 256): eval logits <= 1e-4 with identical argmax (all 6144 at B = 2048), then ONE
+    full training step (teacher forcing mixed, no dropout): logits, loss (1e-5), every parameter gradient, clipped gradient
+    norm and the AdamW-updated weights against the CPU oracle.  The encoder runs the cluster-persistent recurrence
+    (csrc/xps_gru_cluster.hip), the layer GEMMs the 256-tile kernels at B = 2048."""
     from oracle.seq2seq_oracle import Seq2SeqOracle
     from cross_patient_speech_decoding_amd._lib import lib
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
     from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
-    torch.set_num_threads(16)
-    B, C = 256, 30
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    C = 30
     assert lib().xps_gru_seq_status_offset(20, B, H, 2) >= 0          # this shape runs the cluster kernels
     cfg = dict(in_channels=C, n_filters=100, hidden_size=H, n_enc_layers=2, n_dec_layers=1, kernel_size=10,
                stride=10, activation=False)
@@ -277,3 +279,65 @@ def test_north_star_model_shape_vs_oracle(H, gemm_precision):
         keep = gr > 1e-3 * gr.max()
         got, want = got[keep], want[keep]
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+_per_oracle_cache = {}
+
+
+def test_per_parity_at_configs1_shape_100_steps(gemm_precision):
+    """north_star: phoneme error rate within +-0.5 % of the reference CPU path.  configs[1] shape itself (C = 64, F = 100,
+    k = s = 10, H = 128, enc 2 x bi-GRU, dec 1 x GRU, 2048 trials x 200 samples), dropout 0 (deterministic), identical
+    weights and teacher-forcing coins, 100 full-batch AdamW steps (clip 0.5) on the HIP path and on the CPU oracle; then
+    PER by the reference's own formula (realtime_sim/realtime_nn_model.py:318-323: sum of edit distances / sum of target
+    lengths x 100, `phoneme_error_rate`) and the token error 1 - acc (nn_models/models.py:875-889) of the eval-mode
+    predictions of both models on the training trials and on 512 held-out trials."""
+    from oracle.seq2seq_oracle import Seq2SeqOracle, phoneme_error_rate, train_step
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    STEPS, LR = 100, 2.5e-4              # (noise 4.0, 100 steps at this rate: the oracle ends at PER 16.4 % / 19.7 % -- mid-range, sensitive)
+    X, yf = make_patient(0, 2560, T=200, C=64, noise=4.0)
+    X, y = torch.from_numpy(X), torch.from_numpy(yf - 1)
+    Xtr, ytr, Xte, yte = X[:2048], y[:2048], X[2048:], y[2048:]
+    args = (64, 100, 128, 9, 2, 1, 10, 10, 0, 0.0, 0.0)
+    coins = [[bool(c) for c in row] for row in np.random.default_rng(11).integers(0, 2, (STEPS, 3))]
+    if 'ref' not in _per_oracle_cache:                      # the oracle trajectory does not depend on the HIP precision mode
+        orc = Seq2SeqOracle(*args, learning_rate=LR, l2_reg=1e-5, activation=False)
+        orc.load_state_dict(weights_from_seed(orc.state_dict(), 61))
+        opt_o, _ = orc.make_optimizer()
+        losses = [float(train_step(orc, opt_o, Xtr, ytr, coins=coins[i], clip=0.5)[0]) for i in range(STEPS)]
+        orc.eval()
+        with torch.no_grad():
+            ptr = orc(Xtr, ytr, teacher_forcing_ratio=0).argmax(-1).numpy()
+            pte = orc(Xte, yte, teacher_forcing_ratio=0).argmax(-1).numpy()
+        _per_oracle_cache['ref'] = (losses, ptr, pte)
+    losses_o, ptr_o, pte_o = _per_oracle_cache['ref']
+    cfg = dict(in_channels=64, n_filters=100, hidden_size=128, n_enc_layers=2, n_dec_layers=1, kernel_size=10, stride=10,
+               activation=False)
+    hip = build_hip(cfg, 61)
+    opt_h = FlatAdamW(hip, lr=LR, weight_decay=1e-5, max_norm=0.5)
+    Xg, yg = Xtr.cuda(), ytr.cuda()
+    hip.train()
+    losses_h = []
+    for i in range(STEPS):
+        opt_h.zero_grad()
+        logits = hip(Xg, yg, coins=coins[i])
+        lh = hip.criterion(logits.view(-1, 9), yg.view(-1))
+        lh.backward()
+        opt_h.step()
+        losses_h.append(lh)
+    losses_h = [float(v) for v in losses_h]
+    hip.eval()
+    with torch.no_grad():
+        ptr_h = hip(Xg, yg, teacher_forcing_ratio=0).argmax(-1).cpu().numpy()
+        pte_h = hip(Xte.cuda(), yte.cuda(), teacher_forcing_ratio=0).argmax(-1).cpu().numpy()
+    assert losses_o[-1] < 0.8 * losses_o[0], losses_o[::10]                    # the run learned something
+    assert max(abs(a - b) for a, b in zip(losses_h, losses_o)) <= 5e-3, (losses_h[::10], losses_o[::10])
+    for name, ph, po, yy in (('train', ptr_h, ptr_o, ytr.numpy()), ('held-out', pte_h, pte_o, yte.numpy())):
+        per_h, per_o = phoneme_error_rate(ph, yy), phoneme_error_rate(po, yy)
+        tok_h, tok_o = 100.0 * (ph != yy).mean(), 100.0 * (po != yy).mean()
+        print(f'PER {name}: hip {per_h:.3f} oracle {per_o:.3f}; token error hip {tok_h:.3f} oracle {tok_o:.3f}; '
+              f'argmax agreement {100.0 * (ph == po).mean():.3f} %')
+        assert abs(per_h - per_o) <= 0.5, (name, per_h, per_o)                  # north-star tolerance: +-0.5 % absolute
+        assert abs(tok_h - tok_o) <= 0.5, (name, tok_h, tok_o)
+    assert phoneme_error_rate(ptr_o, ytr.numpy()) < 85.0                        # (chance ~ 89 %)
