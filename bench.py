@@ -2,19 +2,23 @@
 """Headline benchmark: ECoG trials/s of seq2seq-GRU training (forward + backward + clip + AdamW)
 on N MI355X GPUs of one node, one process per GPU over RCCL.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: single-patient seq2seq GRU, C=64 channels, T=200 samples,
-Conv1d(k=s=10, F=100) -> T'=20, bidirectional 2-layer GRU encoder H=128, 1-layer GRU decoder,
-3 x 9-way phoneme outputs; one "step" = one full-batch optimisation step over 2048 trials per GPU
-(the reference trains full-batch: batch_size 5000 > dataset, scripts/train_seq2seq.py:100-113),
-dropout 0.3/0.3 and teacher forcing 0.5 as in the reference script.  Weak scaling: every rank
-holds its own 2048-trial shard; BatchNorm statistics and the flat gradient are all-reduced.
+Workload = BASELINE.json configs[3], the configuration the metric and the north-star target are quoted on: the
+cross-patient seq2seq GRU on the MCCA-aligned latent of 8 patients (d = 30 components), T = 200 samples,
+Conv1d(k = s = 10, F = 100) -> T' = 20, bidirectional 2-layer GRU encoder H = 512, 1-layer GRU decoder, 3 x 9-way phoneme
+outputs (reference shape: scripts/train_seq2seq.py:125-138, H = 500 there).  One "step" = one full-batch optimisation step
+(the reference trains full-batch: batch_size 5000 > dataset, scripts/train_seq2seq.py:100-113) over 2048 trials per GPU --
+8 patients x 2048 trials sharded over 8 GPUs -- with dropout 0.3 / 0.3, teacher forcing 0.5, clip 0.5, AdamW as in the
+reference script (:171-189).  Weak scaling: every rank holds its own 2048-trial shard; BatchNorm statistics and the flat
+gradient are all-reduced.  `--workload configs1` measures BASELINE.json configs[1] (single patient, C = 64, H = 128) instead;
+the default run carries it as a sub-record.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and
-`cpu_baseline` (the CPU oracle = torch.nn restatement of the reference, bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel of the step, HIP-event timed) and `cpu_baseline` (the CPU
+oracle = torch.nn restatement of the reference on the SAME full batch, bounded sample) plus sub-records (single process
+only): `configs1`, `fp32`, `alignment` (8 views), `realtime` (config 5) and `dp_rehearsal`.
 """
 import argparse
 import json
@@ -28,11 +32,23 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG = dict(in_channels=64, n_filters=100, hidden_size=128, num_classes=9, n_enc_layers=2, n_dec_layers=1,
-           kernel_size=10, stride=10, T=200, trials_per_gpu=2048)
+BASE = dict(n_filters=100, num_classes=9, n_enc_layers=2, n_dec_layers=1, kernel_size=10, stride=10, T=200, trials_per_gpu=2048)
+WORKLOADS = {
+    'configs3': dict(BASE, in_channels=30, hidden_size=512),
+    'configs1': dict(BASE, in_channels=64, hidden_size=128),
+}
+WORKLOAD_TEXT = {
+    'configs3': "configs[3] per-GPU shard: 8-patient MCCA-aligned input (d = 30), enc 2x bi-GRU H=512, dec 1x GRU, T=200 (T'=20), "
+                'F=100, full-batch step of 2048 trials per GPU (8 patients x 2048 trials over 8 GPUs), dropout 0.3, teacher '
+                'forcing 0.5, clip 0.5, AdamW',
+    'configs1': "configs[1]: single-patient seq2seq GRU, H=128, T=200 (T'=20), C=64, F=100, enc 2x bi-GRU, dec 1x GRU, "
+                'full-batch step of 2048 trials per GPU, dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW',
+}
+PREWARM = {'configs3': 150, 'configs1': 400}
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x4, 64 FLOP/clk/SIMD
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PMC_FILE = os.path.join(ROOT, 'profiles', 'round3', 'pmc_traffic.json')
 
 
 def train_flops_per_trial(c):
@@ -48,9 +64,9 @@ def train_flops_per_trial(c):
     return 3 * fwd
 
 
-def make_data(rank, c):
+def make_data(rank, c, trials=None):
     from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
-    X, y_full = make_patient(rank, c['trials_per_gpu'], T=c['T'], C=c['in_channels'])
+    X, y_full = make_patient(rank, trials or c['trials_per_gpu'], T=c['T'], C=c['in_channels'])
     return torch.from_numpy(X), torch.from_numpy(y_full - 1)           # labels 0..8 (train_seq2seq.py:95)
 
 
@@ -61,11 +77,32 @@ def build_model(c, dropout=0.3):
                       activation=False, decay_iters=500)
 
 
+def _pmc(key):
+    """HBM-side bytes per launch from the PMC passes kept under profiles/round3 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate passes, gfx950 FETCH x2 correction; collected offline by tools/pmc_round3.sh with THIS round's kernels)."""
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f)[key]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(c):
     """The CPU oracle (plain torch.nn restatement of the reference, pinned to reference goldens) on the SAME workload:
     the full batch of 2048 trials per step (the reference trains full-batch), fp32, forward + backward + clip + AdamW.
-    All cores of the GPU's host share (at most 16: oversubscribed small GEMMs run slower): 3 warm-up + 10 timed steps,
-    median; and ONE thread: 1 warm-up + 3 timed steps, median (a bounded sample: a step takes seconds there)."""
+    Thread counts {16, 32, 64} (those the host share offers) are swept, 1 warm-up + 3 timed steps each, the best median is
+    `value`; one thread is timed on a 256-trial batch (a full batch takes ~30 s per step there)."""
     from oracle.seq2seq_oracle import Seq2SeqOracle, train_step
     torch.manual_seed(0)
     m = Seq2SeqOracle(c['in_channels'], c['n_filters'], c['hidden_size'], c['num_classes'], c['n_enc_layers'],
@@ -75,27 +112,33 @@ def cpu_baseline(c):
     X, y = make_data(0, c)
     B = X.shape[0]
 
-    def run(threads, warm, timed):
+    def run(threads, warm, timed, xb, yb):
         torch.set_num_threads(threads)
         for _ in range(warm):
-            train_step(m, opt, X, y, coins=[True, False, True])
+            train_step(m, opt, xb, yb, coins=[True, False, True])
         ts = []
         for _ in range(timed):
             t0 = time.perf_counter()
-            train_step(m, opt, X, y, coins=[True, False, True])
+            train_step(m, opt, xb, yb, coins=[True, False, True])
             ts.append(time.perf_counter() - t0)
         ts.sort()
-        return ts[len(ts) // 2], sum(ts)
-    threads = min(16, os.cpu_count() or 1)
+        return ts[len(ts) // 2]
+    avail = len(os.sched_getaffinity(0))
+    counts = sorted({min(n, avail) for n in (16, 32, 64)})
     t0 = time.perf_counter()
-    med_all, _ = run(threads, 3, 10)
-    med_one, _ = run(1, 1, 3)
+    sweep = {n: run(n, 1, 3, X, y) for n in counts}
+    best = min(sweep, key=sweep.get)
+    sub = 256
+    med_one = run(1, 1, 2, X[:sub], y[:sub])
     el = time.perf_counter() - t0
-    return {'value': round(B / med_all, 1), 'unit': 'trials/s', 'cores': threads, 'kind': 'port',
-            'sample': f'full batch of {B} trials per step (fwd+bwd+clip+AdamW), same architecture/T/C, fp32 torch.nn CPU oracle: '
-                      f'{threads} threads, 3 warm-up + 10 timed steps, median {med_all * 1e3:.0f} ms/step; whole baseline {el:.0f} s',
-            'one_thread': {'value': round(B / med_one, 1), 'unit': 'trials/s', 'cores': 1,
-                           'sample': f'1 warm-up + 3 timed steps, median {med_one * 1e3:.0f} ms/step'}}
+    return {'value': round(B / sweep[best], 1), 'unit': 'trials/s', 'cores': best, 'kind': 'port',
+            'cpu_model': cpu_model_name(), 'host_cores_available': avail, 'host_cores_total': os.cpu_count(),
+            'sample': f'full batch of {B} trials per step (fwd+bwd+clip+AdamW), same architecture / T / d as the GPU workload, fp32 torch.nn '
+                      f'CPU oracle; thread sweep {counts}: 1 warm-up + 3 timed steps each, median; best = {best} threads, '
+                      f'{sweep[best] * 1e3:.0f} ms/step; whole baseline {el:.0f} s',
+            'thread_sweep': {str(n): {'ms_per_step': round(t * 1e3, 1), 'trials_per_s': round(B / t, 1)} for n, t in sweep.items()},
+            'one_thread': {'value': round(sub / med_one, 1), 'unit': 'trials/s', 'cores': 1,
+                           'sample': f'{sub}-trial batch, 1 warm-up + 2 timed steps, median {med_one * 1e3:.0f} ms/step'}}
 
 
 def _event_time(fn, iters=20, warm=3):
@@ -136,11 +179,12 @@ def capture_dominant_launch(step_fn):
     return max(seen, key=lambda t: t[0]) if seen else None
 
 
-def time_dominant_kernel(model, c, captured=None):
-    """Roofline of the kernel with the largest share of the step (profiles/round1/r1c_*): the fp32-MFMA
-    GEMM tile kernel, measured on its largest single launch = the grouped weight-gradient GEMM of encoder
-    layer 1 (6 problems, K = T'*B rows).  Algorithmic FLOPs = sum 2*M*N*K over the group.  The fused GRU
-    recurrence (second largest) is reported beside it."""
+def roofline_wgrad(model, c, captured=None):
+    """Roofline of the dominant launch of the configs[1] step: the grouped weight-gradient GEMM of encoder layer 1 (6 problems
+    dW_hh / dW_ih / biases of both directions, K = T'*B rows, ONE split-K launch + its reduce pass), re-issued on the operands
+    captured from a real backward pass.  bf16x3 mode: priced against HBM (algorithmic bytes = every operand row of dgi, dghn,
+    x, h_prev read once + gradients written), MFMA side beside it; fp32 mode: against the fp32 matrix peak.  `also` = the
+    resident GRU forward kernel of one encoder layer."""
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
     Tp = (c['T'] - c['kernel_size']) // c['stride'] + 1
     B, H = c['trials_per_gpu'], c['hidden_size']
@@ -176,7 +220,6 @@ def time_dominant_kernel(model, c, captured=None):
         operands = 'operands captured from a training step'
     ach = flops / dur / 1e12
     precision = XF.get_gemm_precision()
-    # second: the fused GRU recurrence of one encoder layer (both directions, one launch)
     rnn = model.encoder.rnn
     w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
     b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
@@ -184,17 +227,7 @@ def time_dominant_kernel(model, c, captured=None):
     dur_gru = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True))
     fl_gru = 2 * Tp * B * 2 * 3 * H * H
     by_gru = 4 * 2 * Tp * B * (3 * H + H + 4 * H)          # gi in, y + saved gates (r, z, n, q) out
-    # HBM traffic of this launch from the PMC counters (collected offline with rocprofv3 --pmc, separate passes,
-    # gfx950 FETCH_SIZE correction applied): profiles/round1/pmc_traffic.json
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'round1', 'pmc_traffic.json')) as f:
-            key = 'gemm_tn_grouped_kernel' + ('' if precision == 'fp32' else '_' + precision)
-            traffic = json.load(f)[key]['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        pass
-    # algorithmic HBM bytes of the launch: every operand row read once (dgi, dghn, x, h_prev of both directions),
-    # gradients written once
+    traffic = _pmc('gemm_tn_grouped_kernel' + ('' if precision == 'fp32' else '_' + precision))
     bytes_alg = 4 * (K * (2 * 3 * H + 2 * H + In + 2 * H) + 2 * (3 * H * H + 3 * H * In + 6 * H))
     common = {'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops, 'bytes_per_launch': bytes_alg, 'operands': operands,
               'traffic': traffic, 'precision': precision,
@@ -209,8 +242,6 @@ def time_dominant_kernel(model, c, captured=None):
                        'achieved': round(fl_gru / dur_gru / 1e12, 3), 'frac': round(fl_gru / dur_gru / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                        'launch_us': round(dur_gru * 1e6, 1), 'flops_per_launch': fl_gru}
         return out
-    # bf16 split products: three bf16 MFMAs per algorithmic multiply-add.  The matrix pipe is no longer what binds
-    # (issued MFMA work = 3 * flops is reported beside it); the launch is priced against HBM: algorithmic bytes / time.
     gbs = bytes_alg / dur / 1e9
     out = {'bound': 'hbm', 'kernel': 'gemm_tn_grouped_kernel<bf16x3> (128x128x16 tile, operands split hi/lo while staged, 3 bf16 '
                                      'MFMAs per product; encoder layer-1 weight gradients, 6 problems in one launch, incl. its reduce pass)',
@@ -225,6 +256,58 @@ def time_dominant_kernel(model, c, captured=None):
     return out
 
 
+def roofline_cluster(model, c, dev):
+    """Roofline of the dominant kernel of the configs[3] step: the cluster-persistent BPTT launch of one bidirectional H = 512
+    layer (20 steps, 2048 trials, ONE launch; two such launches per step), HIP-event timed on the launch stream.  HBM-bound
+    by design: W_hh stays in registers, what must move is the saved gates, dy and h_prev in, dgi and dghn out (algorithmic
+    bytes below; the in-kernel exchange of gate gradients is on-chip traffic and not counted as algorithmic).  `traffic` = the
+    PMC-measured HBM-side bytes of the same launch; `also` = the forward launch and the largest 256-tile GEMM (MFMA side)."""
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    B, H = c['trials_per_gpu'], c['hidden_size']
+    Tp = (c['T'] - c['kernel_size']) // c['stride'] + 1
+    rnn = model.encoder.rnn
+    w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
+    b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
+    gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
+    dy = torch.randn(Tp, B, 2 * H, device=dev) * 0.1
+    t_f = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True), iters=10)
+    y_ext, saved = XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True)
+    split = XF.split4_wanted(Tp, B, H, 2)
+    t_b = _event_time(lambda: XF._gru_backward(dy, None, y_ext, saved, w_hh, Tp, B, H, 2, False, split4=split), iters=10)
+    torch.cuda.synchronize()
+    XF.check_gru_status()
+    by_f = 4 * 2 * Tp * B * (3 * H + H + 4 * H)              # gi in, h + saved gates (r, z, n, q) out
+    by_b = 4 * 2 * Tp * B * (4 * H + H + H + 3 * H + H)      # saved gates, dy, h_prev in; dgi, dghn out
+    fl_rec = 2.0 * 2 * Tp * B * 3 * H * H
+    sfx = '_bf16x3' if XF.get_gemm_precision() == 'bf16x3' else ''
+    tr_b, tr_f = _pmc('gru_cluster_bwd_kernel' + sfx), _pmc('gru_cluster_fwd_kernel' + sfx)
+    # the largest GEMM of the step beside it: dW_ih of encoder layer 1 (3H x 2H x T'B), the 256-tile TN kernel incl. its reduce
+    K, In = Tp * B, 2 * H
+    A = torch.randn(K, 3 * H, device=dev) * 0.1
+    Bm = torch.randn(K, In, device=dev)
+    Cw, cb = torch.empty(3 * H, In, device=dev), torch.empty(3 * H, device=dev)
+    t_g = _event_time(lambda: XF.gemm_tn_grouped([XF.tn_problem(A, Bm, Cw, 3 * H, In, K, colsum_out=cb)], dev), iters=10)
+    fl_g = 2.0 * 3 * H * In * K
+    issued = 3 if sfx else 1
+    peak = BF16_MFMA_PEAK_TFLOPS if sfx else F32_MFMA_PEAK_TFLOPS
+    out = {'bound': 'hbm', 'kernel': 'gru_cluster_bwd_kernel (BPTT of one bidirectional H = 512 layer, 20 steps, 2048 trials, ONE launch: '
+                                     'W_hh^T resident in the registers of 16-workgroup clusters, gate gradients exchanged in-kernel)',
+           'achieved': round(by_b / t_b / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by_b / t_b / 1e9 / HBM_PEAK_GBS, 4),
+           'launch_us': round(t_b * 1e6, 1), 'bytes_per_launch': by_b, 'flops_per_launch': fl_rec, 'traffic': tr_b,
+           'traffic_ratio': round(tr_b / by_b, 3) if tr_b else None,
+           'precision': XF.get_gemm_precision(), 'operands': 'random normal operands of the step\'s shapes',
+           'also': [{'kernel': 'gru_cluster_fwd_kernel (same layer, forward, gates saved)', 'bound': 'hbm',
+                     'achieved': round(by_f / t_f / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), 'launch_us': round(t_f * 1e6, 1),
+                     'bytes_per_launch': by_f, 'flops_per_launch': fl_rec, 'traffic': tr_f,
+                     'traffic_ratio': round(tr_f / by_f, 3) if tr_f else None},
+                    {'kernel': 'gemm_big_tn_kernel + reduce (dW_ih of encoder layer 1: 1536 x 1024 x 40960, 256 x 256 tiles)', 'bound': 'mfma',
+                     'achieved': round(issued * fl_g / t_g / 1e12, 1), 'peak': peak, 'unit': 'TFLOP/s (issued MFMA work)',
+                     'frac': round(issued * fl_g / t_g / 1e12 / peak, 4), 'launch_us': round(t_g * 1e6, 1), 'flops_per_launch': fl_g,
+                     'algorithmic_tflops': round(fl_g / t_g / 1e12, 1)}]}
+    return out
+
+
 def _timed_steps(step, steps, warm):
     for _ in range(warm):
         step()
@@ -236,84 +319,82 @@ def _timed_steps(step, steps, warm):
     return (time.perf_counter() - t0) / steps
 
 
-def _make_step(c, dev, rank, dropout=0.3):
-    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
-    torch.manual_seed(1234)
-    model = build_model(c, dropout).to(dev)
-    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5)
-    X, y = make_data(rank, c)
-    X, y = X.to(dev), y.to(dev)
-    model.train()
+def _make_step(c, dev, rank, dropout=0.3, group=None, world=1):
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    model = build_model(c, dropout).to(dev)
+    if group is not None:
+        model.temporal_conv.process_group = group
+        model.temporal_conv.global_batch = c['trials_per_gpu'] * world
+    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5, group=group)
+    X, y = make_data(rank, c)
+    X, y = X.to(dev), y.to(dev)                  # inputs resident in HBM before any timed region
+    model.train()
     one = XF.unit_gradient(dev)
 
     def step():
         opt.zero_grad()
         logits = model(X, y, teacher_forcing_ratio=0.5)
         loss = model.criterion(logits.view(-1, c['num_classes']), y.view(-1))
-        loss.backward(one)
+        loss.backward(one)                       # a resident 1.0 as the root gradient (autograd would launch a fill)
         opt.step()
         return loss
     return model, step
 
 
-def north_star_shard(dev, steps=10, warm=10):
-    """Second record: the per-GPU shard of configs[3] (8-patient MCCA + bidirectional 2-layer GRU, H = 512, on 8 GPUs): 2048
-    trials per GPU and step of the aligned d = 30 latent input, F = 100, k = s = 10 (T' = 20), enc 2 x bi-GRU H = 512, dec
-    1 x GRU.  Same step function as the headline (dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW), single GPU, no
-    collective; the recurrence runs the cluster-persistent kernels (csrc/xps_gru_cluster.hip), timed alone beside it."""
+def workload_record(name, dev, steps, warm, with_roofline=True):
+    """A sub-record: the named workload in a fresh model, single GPU, the same step function as the headline."""
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
-    c = dict(CFG, in_channels=30, hidden_size=512)
+    c = WORKLOADS[name]
     model, step = _make_step(c, dev, 0)
-    dt = _timed_steps(step, steps, warm)
+    dt = _timed_steps(step, steps, warm + PREWARM[name] // 4)
     XF.check_gru_status()
     fl = train_flops_per_trial(c)
-    B, H, Tp = c['trials_per_gpu'], 512, 20
-    rnn = model.encoder.rnn
-    w_hh = [rnn.weight_hh_l1.detach().contiguous(), rnn.weight_hh_l1_reverse.detach().contiguous()]
-    b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
-    gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
-    dy = torch.randn(Tp, B, 2 * H, device=dev) * 0.1
-    t_f = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True), iters=10)
-    y_ext, saved = XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True)
-    t_b = _event_time(lambda: XF._gru_backward(dy, None, y_ext, saved, w_hh, Tp, B, H, 2, False), iters=10)
-    XF.check_gru_status()
-    by_f = 4 * 2 * Tp * B * (3 * H + H + 4 * H)              # gi in, h + saved gates (r, z, n, q) out
-    by_b = 4 * 2 * Tp * B * (4 * H + H + H + 3 * H + H)      # saved gates, dy, h_prev in; dgi, dghn out
-    fl_rec = 2.0 * 2 * Tp * B * 3 * H * H
-    traffic = {}
-    try:                                   # HBM-side bytes per launch from the PMC passes kept under profiles/round2 (collected offline)
-        with open(os.path.join(ROOT, 'profiles', 'round2', 'pmc_traffic.json')) as f:
-            pj = json.load(f)
-        sfx = '_bf16x3' if XF.get_gemm_precision() == 'bf16x3' else ''
-        traffic = {'bwd': pj['gru_cluster_bwd_kernel' + sfx]['hbm_bytes_per_launch'], 'fwd': pj['gru_cluster_fwd_kernel' + sfx]['hbm_bytes_per_launch']}
-    except (OSError, KeyError, ValueError):
-        pass
-    return {
-        'workload': 'configs[3] per-GPU shard: 8-patient MCCA-aligned input (d = 30), enc 2x bi-GRU H=512, dec 1x GRU, T=200 '
-                    "(T'=20), F=100, 2048 trials per GPU and step, dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW; 1 GPU, no collective",
-        'value': round(B / dt, 1), 'unit': 'trials/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'warmup': warm,
-        'train_mflop_per_trial': round(fl / 1e6, 2), 'model_tflops': round(B / dt * fl / 1e12, 2),
-        'dtype': 'bf16x3' if XF.get_gemm_precision() == 'bf16x3' else 'f32',
-        'roofline': {'bound': 'hbm', 'kernel': 'gru_cluster_bwd_kernel (BPTT of one bidirectional H = 512 layer, 20 steps, ONE launch: '
-                                               'W_hh resident in a 16-workgroup cluster, gate gradients exchanged in-kernel)',
-                     'achieved': round(by_b / t_b / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by_b / t_b / 1e9 / HBM_PEAK_GBS, 4),
-                     'launch_us': round(t_b * 1e6, 1), 'bytes_per_launch': by_b, 'flops_per_launch': fl_rec, 'traffic': traffic.get('bwd'),
-                     'also': {'kernel': 'gru_cluster_fwd_kernel (same layer, forward, gates saved)', 'bound': 'hbm',
-                              'achieved': round(by_f / t_f / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), 'launch_us': round(t_f * 1e6, 1),
-                              'bytes_per_launch': by_f, 'flops_per_launch': fl_rec, 'traffic': traffic.get('fwd')}}}
+    B = c['trials_per_gpu']
+    out = {'workload': WORKLOAD_TEXT[name], 'value': round(B / dt, 1), 'unit': 'trials/s', 'ms_per_step': round(dt * 1e3, 3),
+           'steps': steps, 'warmup': warm + PREWARM[name] // 4, 'train_mflop_per_trial': round(fl / 1e6, 2),
+           'model_tflops': round(B / dt * fl / 1e12, 2), 'dtype': 'bf16x3' if XF.get_gemm_precision() == 'bf16x3' else 'f32'}
+    if with_roofline:
+        out['roofline'] = (roofline_wgrad(model, c, capture_dominant_launch(step)) if name == 'configs1'
+                           else roofline_cluster(model, c, dev))
+    return out
+
+
+def fp32_record(name, dev, steps, warm):
+    """The headline workload with the matrix kernels in exact-fp32 MFMA mode (the reference's own arithmetic), priced
+    against the 157.3 TFLOP/s fp32 matrix peak."""
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    c = WORKLOADS[name]
+    old = XF.get_gemm_precision()
+    XF.set_gemm_precision('fp32')
+    try:
+        _, step = _make_step(c, dev, 0)
+        dt = _timed_steps(step, steps, warm)
+        XF.check_gru_status()
+    finally:
+        XF.set_gemm_precision(old)
+    fl = train_flops_per_trial(c)
+    tf = c['trials_per_gpu'] / dt * fl / 1e12
+    return {'workload': name, 'dtype': 'f32', 'ms_per_step': round(dt * 1e3, 3), 'value': round(c['trials_per_gpu'] / dt, 1),
+            'unit': 'trials/s', 'model_tflops': round(tf, 2), 'peak_tflops': F32_MFMA_PEAK_TFLOPS,
+            'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4), 'steps': steps, 'warmup': warm}
 
 
 def alignment_record(dev):
-    """Fourth record: latent alignment at the north-star shape (patients of 2048 trials x 200 samples x 128 channels, fp32,
-    resident in HBM like the training inputs): fits / s of the per-patient PCA(0.95), of the pairwise CCA fit on the PCA latents
-    (reference: AlignCCA inside process_aligner, datamodules.py:542-565) and of the 4-view MCCA fit (AlignMCCA.py:140-154);
-    HIP events on the launch stream, median of 5."""
+    """Latent alignment at the north-star shape: EIGHT patients of 2048 trials x 200 samples x 128 channels (fp32, 210 MB each,
+    resident in HBM like the training inputs): fits / s of the per-patient PCA(0.95), of the pairwise CCA fit on the PCA
+    latents (reference: AlignCCA inside process_aligner, datamodules.py:542-565) and of the 8-view MCCA fit on the raw
+    channels (D = 8 x 128 = 1024, n_components 30, regs 0.5; AlignMCCA.py:140-154) -- single process, and the share ONE rank
+    computes when the fit is sharded by patient over 8 ranks (its patient's condition means and block row of the
+    cross-covariance + the replicated eigensolve; the exchanges -- 8 x 13 MB of views, 8 MB of block rows -- not included)."""
     import numpy as np
     from cross_patient_speech_decoding_amd import alignment as A
+    from cross_patient_speech_decoding_amd.alignment import AlignMCCA as M
+    from cross_patient_speech_decoding_amd.alignment import _linalg as LA
+    from cross_patient_speech_decoding_amd.alignment.alignment_utils import _group_conditions_device
     from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
-    P = 4
+    P = 8
     pats = [make_patient(p, 2048, T=200, C=128) for p in range(P)]
     Xd = [torch.from_numpy(x).to(dev) for x, _ in pats]
     ys = [y for _, y in pats]
@@ -336,30 +417,83 @@ def alignment_record(dev):
     t_tr = med(lambda: al.transform(Z[1]))
     m = A.AlignMCCA(n_components=30, regs=0.5)
     t_mcca = med(lambda: m.fit(Xd, ys), n=3)
+
+    # per-rank share of the patient-sharded fit (8 ranks): own condition means + own block row, then the replicated tail
+    own = [i == 0 for i in range(P)]
+    avgs_all = [a.reshape(-1, a.shape[-1]) for a in _group_conditions_device(Xd, ys)]
+    Zc = torch.cat([a.to(LA.F64) for a in avgs_all], dim=1).contiguous()
+    mean = torch.cat([LA.col_mean(a) for a in avgs_all])
+
+    def rank_share():
+        a0 = _group_conditions_device(Xd, ys, own=own)[0]
+        a0 = a0.reshape(-1, a0.shape[-1])
+        return LA.xcov(a0, Zc, mean[:128].contiguous(), mean)
+    t_share = med(rank_share, n=3)
+    G = torch.cat([LA.xcov(avgs_all[i], Zc, mean[128 * i:128 * (i + 1)].contiguous(), mean) for i in range(P)], dim=0).cpu().numpy()
+    offs = np.arange(P + 1) * 128
+    t_tail = med(lambda: M._gevp(G, offs, 30, 0.5), n=3)
     by = Xd[0].numel() * 4
-    return {'workload': 'north-star patients (2048 trials x 200 x 128 ch fp32 = 210 MB each), inputs resident in HBM',
+    return {'workload': 'north-star patients: 8 x (2048 trials x 200 x 128 ch fp32 = 210 MB), inputs resident in HBM',
             'pca_fit': {'ms': round(t_pca * 1e3, 2), 'fits_per_s': round(1 / t_pca, 1), 'input_GB_per_s': round(by / t_pca / 1e9, 1)},
             'cca_fit': {'ms': round(t_cca * 1e3, 2), 'fits_per_s': round(1 / t_cca, 1), 'latent_dims': [int(Z[0].shape[-1]), int(Z[1].shape[-1])]},
             'cca_transform': {'ms': round(t_tr * 1e3, 2)},
-            'mcca_fit_4_views': {'ms': round(t_mcca * 1e3, 2), 'fits_per_s': round(1 / t_mcca, 2), 'D': 4 * 128}}
+            'mcca_fit_8_views': {'D': P * 128, 'n_components': 30, 'single_process_ms': round(t_mcca * 1e3, 2),
+                                 'fits_per_s': round(1 / t_mcca, 2),
+                                 'per_rank_of_8': {'own_condition_means_and_block_row_ms': round(t_share * 1e3, 2),
+                                                   'replicated_eigensolve_ms': round(t_tail * 1e3, 2),
+                                                   'compute_ms': round((t_share + t_tail) * 1e3, 2),
+                                                   'exchanged_bytes': int(P * avgs_all[0].numel() * 8 + (P * 128) ** 2 * 8)}}}
 
 
-def fp32_record(c, dev, steps=20, warm=30):
-    """Third record: the headline workload with the matrix kernels in exact-fp32 MFMA mode (the reference's own arithmetic),
-    priced against the 157.3 TFLOP/s fp32 matrix peak."""
+def realtime_record(dev):
+    """BASELINE.json configs[4] (config 5 of the survey): streaming decode, one 20 ms step = one 14-sample window of C = 128
+    channels (1792 inputs) through a 2-layer GRU H = 128 + Linear(11), batch 1, replayed from a hipGraph (window upload
+    included).  The reference's one published latency: 2.06 ms per prediction (figure_analyses/supp/supp_fig_24.ipynb cell 23)."""
+    from cross_patient_speech_decoding_amd.realtime_sim import RealtimeRNNModel, StreamingDecoder
+    torch.manual_seed(0)
+    m = RealtimeRNNModel(14 * 128, 128, 2, 11, dropout=0.0).to(dev).eval()
+    dec = StreamingDecoder(m, n_streams=1, use_graph=True)
+    win = torch.randn(1, 14 * 128, device=dev)
+    for _ in range(50):
+        dec.step(win)
+    torch.cuda.synchronize()
+    n = 500
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dec.step(win)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / n * 1e6
+    return {'workload': 'configs[4] streaming decode: C=128 (1792-wide window), GRU H=128 L=2 + Linear(11), batch 1, one hipGraph replay per 20 ms step',
+            'us_per_step': round(us, 1), 'steps': n, 'reference_published_ms_per_prediction': 2.06,
+            'vs_reference_published': round(2060.0 / us, 1)}
+
+
+def dp_rehearsal_record(name, dev, steps, warm):
+    """What the data-parallel host path costs per step, measured where no second GPU exists: the same workload on a ONE-rank
+    RCCL communicator (init_process_group('nccl', device_id=), SyncBN exchanges, ReduceOp.AVG all-reduce of the flat gradient
+    in two pieces, the tail issued asynchronously from the autograd thread) against the plain single-process step, both in
+    this process, same weights.  The product's rule is "data-parallel paths for more than one rank"; this measurement
+    replaces that rule from the outside (XF._dp_enabled) for its own duration."""
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
-    old = XF.get_gemm_precision()
-    XF.set_gemm_precision('fp32')
+    c = WORKLOADS[name]
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
+    _, plain = _make_step(c, dev, 0)
+    dt_plain = _timed_steps(plain, steps, warm)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    real = XF._dp_enabled
+    XF._dp_enabled = lambda group: group is not None
     try:
-        _, step = _make_step(c, dev, 0)
-        dt = _timed_steps(step, steps, warm)
+        _, dp = _make_step(c, dev, 0, group=dist.group.WORLD, world=1)
+        dt_dp = _timed_steps(dp, steps, warm)
+        XF.check_gru_status()
     finally:
-        XF.set_gemm_precision(old)
-    fl = train_flops_per_trial(c)
-    tf = c['trials_per_gpu'] / dt * fl / 1e12
-    return {'dtype': 'f32', 'ms_per_step': round(dt * 1e3, 3), 'value': round(c['trials_per_gpu'] / dt, 1), 'unit': 'trials/s',
-            'model_tflops': round(tf, 2), 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4),
-            'steps': steps, 'warmup': warm}
+        XF._dp_enabled = real
+        XF.POST_SYNCBN_HOOKS[:] = []
+        dist.destroy_process_group()
+    return {'workload': name, 'plain_ms_per_step': round(dt_plain * 1e3, 3), 'one_rank_rccl_ms_per_step': round(dt_dp * 1e3, 3),
+            'dp_overhead_pct': round((dt_dp / dt_plain - 1.0) * 100.0, 2), 'steps': steps, 'warmup': warm,
+            'collectives_per_step': 'SyncBN fwd + bwd statistics (2 x 2F floats), flat-gradient all-reduce in two pieces (tail async)'}
 
 
 def _set_affinity_all_threads(cores):
@@ -374,35 +508,56 @@ def _set_affinity_all_threads(cores):
         pass
 
 
+def _gpu_local_cpus(local_rank):
+    """CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI device), or None."""
+    try:
+        out = os.popen('rocm-smi --showbus --json 2>/dev/null').read()
+        bus = json.loads(out)[f'card{local_rank}']['PCI Bus'].lower()
+        with open(f'/sys/bus/pci/devices/{bus}/local_cpulist') as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(','):
+            a, _, b = part.partition('-')
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except Exception:                                                        # noqa: BLE001
+        return None
+
+
 def pin_host_threads(local_rank):
     """One trainer process per GPU, pinned to a few cores of its own (XPS_BENCH_PIN_CORES, default 4; 0 = leave the scheduler
-    alone).  The enqueue path of a step needs ~1.0 ms of host time against ~1.05 ms of GPU time, so a main or autograd thread
-    that migrates across a 256-core host shows up in a 20-step window: tools/jitter.py, 150 windows in one process:
-    unpinned p90 / p97 / max = 1.124 / 1.347 / 1.638 ms per step (median 1.082), pinned to 2-4 cores 1.08 / 1.09 / 1.19-1.33.
-    Returns the original mask (restored for the CPU-baseline leg, which wants all cores)."""
+    alone), taken from the NUMA node of ITS GPU when sysfs says which that is (else from the affinity mask in order).  The
+    enqueue path of a step needs ~1 ms of host time, so a main or autograd thread that migrates across a 256-core host shows
+    up in short timing windows (tools/jitter.py).  Returns (original mask, description of the pinning for the JSON line)."""
     full = os.sched_getaffinity(0)
     n = int(os.environ.get('XPS_BENCH_PIN_CORES', '4'))
-    if n > 0:
-        cores = sorted(full)
-        sel = cores[local_rank * n:(local_rank + 1) * n]
-        if len(sel) == n:
-            _set_affinity_all_threads(set(sel))
-    return full
+    if n <= 0:
+        return full, 'none'
+    local = _gpu_local_cpus(local_rank)
+    pool = sorted(full & local) if local else []
+    src = 'gpu-numa-node'
+    if len(pool) < n:
+        pool, src = sorted(full), 'affinity-order'
+    # ranks whose GPUs share a node take consecutive slices of that node's cores
+    k = local_rank % max(len(pool) // n, 1)
+    sel = pool[k * n:(k + 1) * n]
+    if len(sel) != n:
+        return full, 'none'
+    _set_affinity_all_threads(set(sel))
+    return full, f'{n} cores ({src}): {sel}'
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # defaults: 200 timed steps (~0.2 s) -- with 20 (a 22-ms window) one host-side hiccup of a few ms moved the headline by 10-25 %
-    # (1.04-1.06 ms/step typical, single runs at 1.27-1.6 seen); the enqueue path leaves the host ~15 % of slack per step
-    ap.add_argument('--steps', type=int, default=200)
+    # defaults: 100 timed configs[3] steps (~0.7 s): short windows wobbled 10-25 % when the host hiccuped once
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='configs3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--headline-only', action='store_true', help='skip the configs[3] shard and fp32 sub-records')
+    ap.add_argument('--headline-only', action='store_true', help='skip the sub-records')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default=None,
                     help='product precision of the matrix kernels (default: the library default, bf16x3)')
-    ap.add_argument('--hidden', type=int, default=None, help='(exploration only) override the hidden size, e.g. 512 = cfg 4')
-    ap.add_argument('--channels', type=int, default=None, help='(exploration only) override the input channels')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -410,61 +565,34 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
-    full_affinity = pin_host_threads(local_rank)
+    full_affinity, pinning = pin_host_threads(local_rank)
     # rehearsal knobs (1-GPU box): XPS_BENCH_BACKEND=gloo XPS_BENCH_ONE_DEVICE=1 put every rank on cuda:0
     backend = os.environ.get('XPS_BENCH_BACKEND', 'nccl')
     if os.environ.get('XPS_BENCH_ONE_DEVICE'):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    # rehearsal knob (1-GPU box): XPS_BENCH_FORCE_DP=1 (+ XPS_DP_SINGLE_RANK_COLLECTIVES=1) runs the data-parallel code path --
-    # SyncBN exchanges, flat-gradient all-reduces, hooks -- on a ONE-rank RCCL communicator: what the DP host path costs per step
-    force_dp = world == 1 and os.environ.get('XPS_BENCH_FORCE_DP') == '1'
-    if force_dp:
-        os.environ.setdefault('MASTER_PORT', '29577')
-    if world > 1 or force_dp:
+    if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
     if args.precision:
         XF.set_gemm_precision(args.precision)
     precision = XF.get_gemm_precision()
-    c = dict(CFG)
-    if args.hidden:
-        c['hidden_size'] = args.hidden
-    if args.channels:
-        c['in_channels'] = args.channels
-    explore = bool(args.hidden or args.channels)
-    torch.manual_seed(1234)                      # identical initial weights on every rank
-    model = build_model(c).to(dev)
-    if world > 1 or force_dp:
-        model.temporal_conv.process_group = dist.group.WORLD
-        model.temporal_conv.global_batch = c['trials_per_gpu'] * world
-    opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5, group=dist.group.WORLD if (world > 1 or force_dp) else None)
-    X, y = make_data(rank, c)
-    X, y = X.to(dev), y.to(dev)                  # inputs resident in HBM before the timed region
+    name = args.workload
+    c = dict(WORKLOADS[name])
+    model, step = _make_step(c, dev, rank, group=dist.group.WORLD if world > 1 else None, world=world)
     torch.manual_seed(99)                        # the same teacher-forcing coins on every rank
-    model.train()
 
-    one = XF.unit_gradient(dev)
-
-    def step():
-        opt.zero_grad()
-        logits = model(X, y, teacher_forcing_ratio=0.5)
-        loss = model.criterion(logits.view(-1, c['num_classes']), y.view(-1))
-        loss.backward(one)                       # a resident 1.0 as the root gradient (autograd would launch a fill)
-        opt.step()
-        return loss
-
-    # untimed pre-warm: the first second of a fresh process runs slower on this pool (clock ramp / cold code pages: 2.9 vs
-    # 1.8 ms/step measured); it is spent here, BEFORE the W warm-up steps of the contract, never inside the timed region
+    # untimed pre-warm: the first second of a fresh process runs slower on this pool (clock ramp / cold code pages); it is
+    # spent here, BEFORE the W warm-up steps of the contract, never inside the timed region, and stated in the JSON line
     # (a fixed STEP count, so that every rank of a data-parallel run issues the same collectives)
-    for _ in range(int(os.environ.get('XPS_BENCH_PREWARM_STEPS', '400'))):
+    prewarm = int(os.environ.get('XPS_BENCH_PREWARM_STEPS', str(PREWARM[name])))
+    for _ in range(prewarm):
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -474,8 +602,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     import gc
-    if os.environ.get('XPS_BENCH_COLLECT', '0') == '1':
-        gc.collect()
     if os.environ.get('XPS_BENCH_GC', '0') != '1':
         gc.disable()                             # no collector pauses inside the timed region (they gate every rank under DP)
     t0 = time.perf_counter()
@@ -487,6 +613,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     gc.enable()
+    XF.check_gru_status()                        # (outside the timed region: one small device word)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -499,41 +626,45 @@ def main():
         fl = train_flops_per_trial(c)
         out = {
             'metric': 'ECoG trials/sec seq2seq-RNN training', 'value': round(value, 1), 'unit': 'trials/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'prewarm_steps': prewarm,
             'ms_per_step': round(el / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             # bf16x3: every fp32 operand split hi + lo in bf16, 3 bf16 MFMAs per product, fp32 accumulation and fp32 everywhere
             # else (results within 2e-6 of the fp32 reference goldens); fp32: fp32 MFMA
             'dtype': 'bf16x3' if precision == 'bf16x3' else 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'configs[1]: single-patient seq2seq GRU, H=128, T=200 (T\'=20), C=64, F=100, '
-                                   'enc 2x bi-GRU, dec 1x GRU, full-batch step of 2048 trials per GPU, '
-                                   'dropout 0.3, teacher forcing 0.5, clip 0.5, AdamW',
+            'config': {'workload': WORKLOAD_TEXT[name],
                        'trials_per_gpu': c['trials_per_gpu'], 'global_batch': c['trials_per_gpu'] * world,
                        'parallelism': f'dp{world}', 'train_mflop_per_trial': round(fl / 1e6, 2),
                        'precision': ('bf16x3 = fp32 operands split hi + lo in bf16, 3 bf16 MFMAs per product, fp32 accumulate and '
-                                     'fp32 everywhere else' if precision == 'bf16x3' else 'fp32 MFMA')},
+                                     'fp32 everywhere else' if precision == 'bf16x3' else 'fp32 MFMA'),
+                       'host_pinning': pinning, 'timed_window_ms': round(el * 1e3, 1)},
             'model_tflops': round(value * fl / 1e12, 3), 'final_loss': round(final_loss, 5),
         }
         out['config']['collective'] = (f'RCCL (torch.distributed backend {backend!r}) world {world}: SyncBN statistics + flat gradient '
                                        f'all-reduce per step' if world > 1 else 'none (single process)')
         out['rccl_world'] = world if (world > 1 and backend == 'nccl') else (0 if world == 1 else None)
-        if not explore:
-            # the capture runs one more training step: single process only (under DP it would issue collectives alone)
-            out['roofline'] = time_dominant_kernel(model, c, capture_dominant_launch(step) if world == 1 else None)
-            if world == 1 and not args.headline_only:
+        if world == 1:
+            # (single process only: the roofline probes re-issue launches, a capture runs one more training step)
+            try:
+                out['roofline'] = (roofline_cluster(model, c, dev) if name == 'configs3'
+                                   else roofline_wgrad(model, c, capture_dominant_launch(step)))
+            except Exception as e:                                           # noqa: BLE001
+                out['roofline'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            if not args.headline_only:
+                other = 'configs1' if name == 'configs3' else 'configs3'
                 # sub-records never cost the headline line: a failure is reported in place of the record
-                for key, fn in (('north_star_shard', lambda: north_star_shard(dev)),
-                                ('fp32', (lambda: fp32_record(c, dev)) if precision != 'fp32' else None),
-                                ('alignment', lambda: alignment_record(dev))):
+                for key, fn in ((other, lambda: workload_record(other, dev, 200 if other == 'configs1' else 100, 20)),
+                                ('fp32', (lambda: fp32_record(name, dev, 30 if name == 'configs3' else 100, 10)) if precision != 'fp32' else None),
+                                ('alignment', lambda: alignment_record(dev)),
+                                ('realtime', lambda: realtime_record(dev)),
+                                ('dp_rehearsal', lambda: dp_rehearsal_record(name, dev, 100, 30))):
                     if fn is None:
                         continue
                     try:
                         out[key] = fn()
                     except Exception as e:                                   # noqa: BLE001
                         out[key] = {'error': f'{type(e).__name__}: {e}'[:300]}
-        else:
-            out['config']['workload'] = f"EXPLORATION (not the headline config): H={c['hidden_size']}, C={c['in_channels']}"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 _set_affinity_all_threads(full_affinity)        # the CPU oracle gets every core of the host share

@@ -27,14 +27,34 @@ class DeviceMCCA:
     def __init__(self, n_components=10, regs=0.5, signal_ranks=None):
         self.n_components, self.regs, self.signal_ranks = n_components, regs, signal_ranks
 
-    def fit(self, views):
-        """views: list of (n, d_b) arrays / device tensors (one row per condition-time sample)."""
-        Vd = [LA.to_device(v).reshape(-1, v.shape[-1]) for v in views]
+    def fit(self, views, group=None):
+        """views: list of (n, d_b) arrays / device tensors (one row per condition-time sample).
+
+        ``group`` (a torch.distributed group with more than one rank): the fit is SHARDED BY PATIENT: view p is
+        owned by rank p % world and only its owner needs to hold it (other entries may be None).  The owners broadcast their
+        views (n x d_p float64: 13 MB at the north-star shape), every rank computes the block rows
+        C_{p,.} = (L_p - mean_p)^T [L_1 - mean_1 ... L_P - mean_P] of ITS views on its own GPU (xps_xcov_f64) and the block rows
+        are exchanged (D x D float64 in all: 8 MB at D = 1024); the eigensolve is replicated (deterministic, no broadcast).
+        The single-process fit computes the same block rows with the same launches, so both give the same bits."""
+        world, rank = _group_world_rank(group)
+        P = len(views)
+        Vd = [None] * P
+        for i, v in enumerate(views):
+            if i % world == rank:
+                t = LA.to_device(v)
+                Vd[i] = t.reshape(-1, t.shape[-1]).to(LA.F64).contiguous()
+        if world > 1:
+            Vd = [_bcast_matrix(Vd[i], i % world, group) for i in range(P)]
         dims = [v.shape[1] for v in Vd]
         offs = np.concatenate([[0], np.cumsum(dims)])
-        Z = LA.torch.cat([v.to(LA.F64) for v in Vd], dim=1).contiguous()
-        mean = LA.col_mean(Z)
-        G = LA.xcov(Z, None, mean).cpu().numpy()              # (D, D) centred Gram, f64 MFMA
+        Z = LA.torch.cat(Vd, dim=1).contiguous()
+        mean = LA.torch.cat([LA.col_mean(v) for v in Vd])
+        # centred Gram of the concatenated views, one block row per view (f64 MFMA); sharded: own rows only, then exchanged
+        rows = [LA.xcov(Vd[i], Z, mean[offs[i]:offs[i + 1]].contiguous(), mean) if i % world == rank else None for i in range(P)]
+        if world > 1:
+            rows = [_bcast_matrix(rows[i], i % world, group) for i in range(P)]
+        G = LA.torch.cat(rows, dim=0).cpu().numpy()           # (D, D)
+        self.block_rows_computed_ = [i for i in range(P) if i % world == rank]
         self.means_ = [mean[offs[i]:offs[i + 1]].cpu().numpy() for i in range(len(Vd))]
         self._means_d = [mean[offs[i]:offs[i + 1]].contiguous() for i in range(len(Vd))]
         bases = None
@@ -79,6 +99,29 @@ def _block_diag(blocks):
         r += b.shape[0]
         c += b.shape[1]
     return out
+
+
+def _group_world_rank(group):
+    if group is None:
+        return 1, 0
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _bcast_matrix(t, owner, group):
+    """Broadcast a 2-D float64 device matrix from rank `owner` of `group` (its shape first); returns it on every rank."""
+    import torch.distributed as dist
+    dev = LA.device()
+    src = dist.get_global_rank(group, owner) if hasattr(dist, 'get_global_rank') else owner
+    shape = LA.torch.tensor(list(t.shape) if t is not None else [0, 0], dtype=LA.torch.int64, device=dev)
+    dist.broadcast(shape, src=src, group=group)
+    if t is None:
+        t = LA.torch.empty(int(shape[0]), int(shape[1]), dtype=LA.F64, device=dev)
+    t = t.contiguous()
+    dist.broadcast(t, src=src, group=group)
+    return t
 
 
 def _gevp(G, offs, n_components, regs):
@@ -133,9 +176,11 @@ class AlignMCCA:
             setattr(self, k, v)
         return self
 
-    def fit(self, X, y):
+    def fit(self, X, y, group=None):
+        """``group``: shard the fit by patient over a torch.distributed group (view p owned by rank p % world; X[p] may be
+        None on the other ranks, y must hold the labels of EVERY view on every rank: they decide the shared conditions)."""
         self.mcca = get_MCCA_transforms(X, y, n_components=self.n_components, regs=self.regs,
-                                        pca_var=self.pca_var)
+                                        pca_var=self.pca_var, group=group)
 
     def transform(self, X, idx=-1):
         if not self._check_fit():
@@ -171,15 +216,23 @@ class AlignMCCA:
         return True
 
 
-def get_MCCA_transforms(features, labels, n_components=10, regs=0.5, pca_var=1):
+def get_MCCA_transforms(features, labels, n_components=10, regs=0.5, pca_var=1, group=None):
     """Condition averages of the shared conditions -> flattened views -> optional per-view signal
-    ranks from the PCA variance of the RAW data (:146-150) -> MCCA fit."""
-    avgs = _group_conditions_device(features, labels)
-    avgs = [a.reshape(-1, a.shape[-1]) for a in avgs]
+    ranks from the PCA variance of the RAW data (:146-150) -> MCCA fit.  ``group``: sharded by patient (see DeviceMCCA.fit):
+    a rank reads the raw trials of ITS views only (condition means, signal ranks)."""
+    world, rank = _group_world_rank(group)
+    own = [i % world == rank for i in range(len(features))]
+    avgs = _group_conditions_device(features, labels, own=own)
+    avgs = [None if a is None else a.reshape(-1, a.shape[-1]) for a in avgs]
     ranks = None
     if pca_var > 0 and pca_var < 1:
-        ranks = [min(n_components, n_components_var(x, pca_var)) for x in features]
-    return DeviceMCCA(n_components=n_components, regs=regs, signal_ranks=ranks).fit(avgs)
+        ranks = [min(n_components, n_components_var(x, pca_var)) if o else 0 for x, o in zip(features, own)]
+        if world > 1:
+            import torch.distributed as dist
+            t = LA.torch.tensor(ranks, dtype=LA.torch.int64, device=LA.device())
+            dist.all_reduce(t, group=group)                  # (every entry is non-zero on exactly one rank)
+            ranks = [int(v) for v in t.cpu()]
+    return DeviceMCCA(n_components=n_components, regs=regs, signal_ranks=ranks).fit(avgs, group=group)
 
 
 def n_components_var(X, var):

@@ -43,12 +43,19 @@ def cnd_avg(data, labels):
     return _cnd_avg_device(data, np.asarray(labels))[1].cpu().numpy()
 
 
-def _group_conditions_device(Xs, ys):
+def _group_conditions_device(Xs, ys, own=None):
+    """own[i] False: view i belongs to another rank (patient-sharded fits): its data is not touched and its entry is None;
+    the labels of EVERY view still decide the shared conditions."""
     keys = [label2str(y) for y in ys]
-    avgs = [_cnd_avg_device(x, k) for x, k in zip(Xs, keys)]
+    own = [True] * len(Xs) if own is None else own
+    avgs = [_cnd_avg_device(x, k) if o else None for x, k, o in zip(Xs, keys, own)]
     shared = reduce(np.intersect1d, keys)
     out = []
-    for uniq, a in avgs:
+    for k, av in zip(keys, avgs):
+        if av is None:
+            out.append(None)
+            continue
+        uniq, a = av
         keep = np.flatnonzero(np.isin(uniq, shared, assume_unique=True))
         out.append(a[LA.torch.from_numpy(keep).to(a.device)])
     return out

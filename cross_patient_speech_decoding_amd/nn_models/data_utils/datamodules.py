@@ -112,6 +112,55 @@ def process_aligner_sharded(X, y, y_align, pool_data, algner, n_components=0.95,
     return torch.Tensor(X_pool), y_pool, tar_dr
 
 
+def process_aligner_multiview_sharded(X, y, y_align, pool_data, algner, n_components=0.95, group=None):
+    """``process_aligner_multiview`` with the PATIENTS sharded over the ranks of ``group`` (P patients
+    <-> P GPUs; view 0 = the target).  View p is owned by rank p % world: its owner runs its PCA, its condition means and its
+    block row of the MCCA cross-covariance on its own GPU (``AlignMCCA.fit(..., group=)``: views and block rows are exchanged,
+    the eigensolve is replicated), maps its own trials into the shared space and broadcasts them (N x T x k float32).  Every
+    rank ends with the pooled set of the single-process function, bit for bit.  ``algner()`` must accept ``fit(Xs, ys,
+    group=)`` (AlignMCCA).  The target map needs the target's PCA on every rank: each fits it (deterministic, 9 ms)."""
+    import torch.distributed as dist
+    if group is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return process_aligner_multiview(X, y, y_align, pool_data, algner, n_components)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    raw = [X] + [x for x, _, _ in pool_data]
+    pcas, views = [None] * len(raw), [None] * len(raw)
+    for i, x in enumerate(raw):
+        if i % world == rank or i == 0:
+            xn = _np(x)
+            pcas[i] = PCA(n_components=n_components)
+            z = pcas[i].fit_transform(xn.reshape(-1, xn.shape[-1]))
+            views[i] = z.reshape(xn.shape[0], -1, z.shape[-1])
+    if y_align is None:
+        y_align = y
+    labs = [_np(y_align)] + [_np(ya) for _, _, ya in pool_data]
+    al = algner()
+    al.fit([v if i % world == rank else None for i, v in enumerate(views)], labs, group=group)
+    shared = []
+    for i in range(len(raw)):
+        owner = i % world
+        src = dist.get_global_rank(group, owner) if hasattr(dist, 'get_global_rank') else owner
+        if rank == owner:
+            out = torch.from_numpy(np.ascontiguousarray(al.transform(views[i], idx=i), dtype=np.float32)).to(dev)
+            shape = torch.tensor(out.shape, dtype=torch.int64, device=dev)
+        else:
+            shape = torch.zeros(3, dtype=torch.int64, device=dev)
+        dist.broadcast(shape, src=src, group=group)
+        if rank != owner:
+            out = torch.empty(tuple(int(v) for v in shape), dtype=torch.float32, device=dev)
+        dist.broadcast(out, src=src, group=group)
+        shared.append(out.cpu().numpy())
+    X_pool = np.vstack(shared)
+    ys = [_np(y)] + [_np(yy) for _, yy, _ in pool_data]
+    y_pool = torch.Tensor(np.vstack(ys) if ys[0].ndim > 1 else np.hstack(ys)).long()
+
+    class _TargetMap:
+        def transform(self, X2d):
+            return al.transform(pcas[0].transform(X2d), idx=0)
+    return torch.Tensor(X_pool), y_pool, _TargetMap()
+
+
 def process_aligner_multiview(X, y, y_align, pool_data, algner, n_components=0.95):
     """Multiview (MCCA / joint-PCA) counterpart: PCA per patient, ONE ``algner()`` fitted on all
     views ([target] + pooled; fit(Xs, ys) / transform(X, idx) API), every view mapped into the shared
@@ -130,7 +179,7 @@ def process_aligner_multiview(X, y, y_align, pool_data, algner, n_components=0.9
     labs = [_np(y_align)] + [_np(ya) for _, _, ya in pool_data]
     al = algner()
     al.fit(views, labs)
-    shared = [al.transform(v, idx=i) for i, v in enumerate(views)]
+    shared = [np.ascontiguousarray(al.transform(v, idx=i), dtype=np.float32) for i, v in enumerate(views)]
     X_pool = np.vstack(shared)
     ys = [_np(y)] + [_np(yy) for _, yy, _ in pool_data]
     y_pool = torch.Tensor(np.vstack(ys) if ys[0].ndim > 1 else np.hstack(ys)).long()

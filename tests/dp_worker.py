@@ -65,6 +65,23 @@ def sharded_alignment(group):
     return Xp.numpy(), yp.numpy(), int(tar.n_components_)
 
 
+def sharded_mcca(group):
+    """(a) AlignMCCA.fit(..., group=) on raw 4-view data with pca_var < 1 (signal ranks from the owners) and (b) the whole
+    PCA -> MCCA -> pool pipeline, patients sharded over `group` (None: single process)."""
+    from cross_patient_speech_decoding_amd.alignment import AlignMCCA
+    from cross_patient_speech_decoding_amd.nn_models.data_utils.datamodules import process_aligner_multiview_sharded
+    pats = _patients()
+    al = AlignMCCA(n_components=5, regs=0.5, pca_var=0.9)
+    al.fit([x for x, _ in pats], [y for _, y in pats], group=group)
+    loads = [np.asarray(l) for l in al.mcca.loadings_]
+    tr = [np.asarray(al.transform(x, idx=i)) for i, (x, _) in enumerate(pats)]
+    (Xt, yt), pool = pats[0], [(torch.from_numpy(x), torch.from_numpy(y - 1), torch.from_numpy(y - 1)) for x, y in pats[1:]]
+    Xp, yp, tmap = process_aligner_multiview_sharded(torch.from_numpy(Xt), torch.from_numpy(yt - 1), torch.from_numpy(yt - 1), pool,
+                                                     lambda: AlignMCCA(n_components=4, regs=0.5), group=group)
+    zt = np.asarray(tmap.transform(Xt.reshape(-1, Xt.shape[-1])[:64]))
+    return loads, tr, list(al.mcca.block_rows_computed_), Xp.numpy(), yp.numpy(), zt
+
+
 def worker(rank, world, device, q):
     if device == 'nccl':
         # the production configuration: one process per GPU, RCCL (backend 'nccl'), device bound at init
@@ -84,6 +101,11 @@ def worker(rank, world, device, q):
         res = sharded_alignment(dist.group.WORLD)
         if rank == 1:                       # a rank that does NOT own the target
             q.put(res)
+    elif device == 'mcca':
+        torch.cuda.set_device(0)
+        res = sharded_mcca(dist.group.WORLD)
+        if rank == world - 1:
+            q.put((rank,) + res)
     elif device == 'cuda':
         torch.cuda.set_device(0)
         res = hip_step(rank, world, X, y, dist.group.WORLD)
@@ -165,6 +187,12 @@ def main():
         X1, y1, k1 = sharded_alignment(None)
         assert ks == k1 and Xs.shape == X1.shape and (ys == y1).all()
         assert (Xs == X1).all(), float(abs(Xs - X1).max())          # deterministic decompositions: identical pooled set
+    if a.device == 'mcca':
+        rank, loads, tr, rows, Xp, yp, zt = res
+        loads1, tr1, rows1, Xp1, yp1, zt1 = sharded_mcca(None)
+        assert rows == [i for i in range(4) if i % a.world == rank] and rows1 == [0, 1, 2, 3], (rows, rows1)   # each rank: ITS block rows only
+        for u, v in zip(loads + tr + [Xp, yp, zt], loads1 + tr1 + [Xp1, yp1, zt1]):
+            assert u.shape == v.shape and (u == v).all(), float(np.abs(u - v).max())       # bit for bit
     if a.device in ('cuda', 'nccl'):
         X, y = data()
         g1, p1, n1, rv1 = [torch.as_tensor(v) if not isinstance(v, float) else v for v in hip_step(0, 1, X, y, None)]

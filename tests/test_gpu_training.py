@@ -164,6 +164,19 @@ def test_patient_sharded_alignment_equals_single_process():
     assert 'DP_OK' in out.stdout
 
 
+@pytest.mark.parametrize('world', [2, 4])
+def test_patient_sharded_mcca_equals_single_process(world):
+    """SURVEY 8e (2), MCCA: views sharded over ranks by patient -- condition means / signal ranks / PCA by the owner, every
+    rank computes the block rows C_{p,.} of ITS views (xps_xcov_f64), block rows exchanged, eigensolve replicated.  Loadings,
+    transforms of every view and the pooled training set of the PCA -> MCCA -> pool pipeline are identical, bit for bit,
+    to the single-process fit (reference call site: alignment/AlignMCCA.py:140-154)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29551 + world), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', str(world), '--device', 'mcca'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert 'DP_OK' in out.stdout
+
+
 def test_train_seq2seq_cli_end_to_end(tmp_path):
     """The counterpart of scripts/train_seq2seq.py: pooled + CCA-aligned k-fold training on synthetic patients."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train_seq2seq.py'), '-pt', 'SYN', '-p', 'True',
