@@ -757,6 +757,30 @@ inline int big_min_tiles() {
     return v;
 }
 
+inline int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
+        return 256;
+    }();
+    return cus;
+}
+// Tile-count quantisation of the one-block-per-CU 256-tile kernels: 640 tiles on 256 CUs are 2.5 rounds that cost 3.  When
+// the last round would be at most three quarters full, the 256-tile launch takes the leading row tiles that fill whole
+// rounds and the trailing rows go to the 128-tile kernels (three blocks per CU: their round is a fraction of a 256-tile
+// round) -- same bits either way (both tile shapes accumulate a product whose k range is not split in the same order).
+// Returns the number of leading ROWS for the 256-tile launch (== M: no split).  XPS_GEMM_BIG_TAIL=0: never split.
+inline int big_split_rows(int M, int tiles_per_row_tile) {
+    static const bool on = [] { const char* e = getenv("XPS_GEMM_BIG_TAIL"); return !(e && e[0] == '0'); }();
+    const int cus = device_cus();
+    const long long mt = M / xps_big::TM, total = mt * tiles_per_row_tile;
+    const long long rounds = total / cus, rem = total % cus;
+    if (!on || rounds < 1 || rem == 0 || rem * 4 > (long long)cus * 3) return M;
+    const long long mb = (rounds * cus) / tiles_per_row_tile;
+    if (mb < 1 || mb >= mt) return M;
+    return (int)(mb * xps_big::TM);
+}
+
 template <bool AK, bool BK>
 int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& rb, const float* A2, const float* B2, int K2,
                 float* C, const RowMap& rc, const float* bias, int M, int N, int K, int accumulate, hipStream_t st) {
@@ -783,7 +807,17 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
                                   big_prepare(gemm_big_kernel<AK, BK, false, 2>, BIG_LDS) && big_prepare(gemm_big_kernel<AK, BK, false, 3>, BIG_LDS) &&
                                   big_prepare(gemm_big_kernel<AK, BK, true>, BIG_LDS32);
         if (ready) {
+            const int Mfull = M;
+            M = big_split_rows(M, N / xps_big::TN);
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN));
+            // the rows behind the whole rounds: 128-tile kernels (the recursion ends there: too few tiles for another 256-tile launch)
+            const int Mtail = Mfull - M;
+            auto run_tail = [&]() -> int {
+                if (Mtail <= 0) return 0;
+                const float* At = AK ? A + (long long)M * ra.ld : A + M;
+                const float* A2t = A2 ? (AK ? A2 + (long long)M * ra.ld : A2 + M) : nullptr;
+                return launch_gemm<AK, BK>(At, ra, B, rb, A2t, B2, K2, C + (long long)M * rc.ld, rc, bias, Mtail, N, K, accumulate, st);
+            };
             if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0 && fmt == 0)
                 hipLaunchKernelGGL((gemm_big_kernel<AK, BK, true>), bgrid, dim3(xps_big::NTHR), BIG_LDS32, st,
                                    A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
@@ -799,7 +833,8 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
             else
                 hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false, 3>), bgrid, dim3(xps_big::NTHR), BIG_LDS, st,
                                    A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
-            return hipGetLastError() == hipSuccess ? 0 : -1;
+            if (hipGetLastError() != hipSuccess) return -1;
+            return run_tail();
         }
     }
 #define XPS_LAUNCH_GEMM(MI_, EDGE_, BF_)                                                                              \
@@ -931,6 +966,8 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
         big_plain(A, ra, M) && rb.rpg >= N && rc.rpg >= M) {
         static const bool ready = big_prepare(gemm_big_nt_multi_kernel<false>, BIG_LDS) && big_prepare(gemm_big_nt_multi_kernel<true>, BIG_LDS32);
         if (ready) {
+            const int Mfull = M;
+            M = big_split_rows(M, (N / xps_big::TN) * nprob);
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN) * nprob);
             if (big_deep_allowed() && K % 32 == 0 && fmt == 0)
                 hipLaunchKernelGGL(gemm_big_nt_multi_kernel<true>, bgrid, dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, A, ra.ld, pm,
@@ -939,6 +976,12 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
                 hipLaunchKernelGGL(gemm_big_nt_multi_kernel<false>, bgrid, dim3(xps_big::NTHR), BIG_LDS,
                                (hipStream_t)stream, A, ra.ld, pm, rb.ld, rc.ld, N, K, nprob, fmt);
             XPS_CHECK_LAUNCH();
+            if (Mfull > M) {
+                // the rows behind the whole rounds: the 128-tile kernels (see big_split_rows)
+                float* Ct[4];
+                for (int i = 0; i < nprob; ++i) Ct[i] = C[i] + (long long)M * rc.ld;
+                return xps_gemm_nt_multi_f32(A + (long long)M * ra.ld, ra_, B, rb_, Ct, rc_, bias, nprob, Mfull - M, N, K, stream);
+            }
             return XPS_OK;
         }
     }

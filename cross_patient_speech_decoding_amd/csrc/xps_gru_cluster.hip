@@ -195,8 +195,8 @@ __device__ inline unsigned cl_lds_base(const unsigned char* smem) {
 __device__ inline void cl_wait_vmcnt(int n) {
     switch (n) {
 #define CL_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        CL_VMCNT_CASE(1) CL_VMCNT_CASE(2) CL_VMCNT_CASE(4) CL_VMCNT_CASE(5) CL_VMCNT_CASE(6) CL_VMCNT_CASE(7) CL_VMCNT_CASE(8)
-        CL_VMCNT_CASE(9) CL_VMCNT_CASE(10) CL_VMCNT_CASE(12) CL_VMCNT_CASE(14) CL_VMCNT_CASE(18)
+        CL_VMCNT_CASE(1) CL_VMCNT_CASE(2) CL_VMCNT_CASE(3) CL_VMCNT_CASE(4) CL_VMCNT_CASE(5) CL_VMCNT_CASE(6) CL_VMCNT_CASE(7) CL_VMCNT_CASE(8)
+        CL_VMCNT_CASE(9) CL_VMCNT_CASE(10) CL_VMCNT_CASE(11) CL_VMCNT_CASE(12) CL_VMCNT_CASE(13) CL_VMCNT_CASE(14) CL_VMCNT_CASE(15) CL_VMCNT_CASE(16) CL_VMCNT_CASE(17) CL_VMCNT_CASE(18) CL_VMCNT_CASE(19) CL_VMCNT_CASE(20)
 #undef CL_VMCNT_CASE
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -999,6 +999,537 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward, TWO-DIMENSIONAL cluster (bf16x3 mode, 384 < H <= 512): the default BPTT kernel of the north-star shape.
+//
+// The kernel above gives every member ALL 3H gate-gradient columns of its trials: 192 KiB of operand image per round of 32
+// trials through the vector-memory path of every CU (1.5 MB per step), three barriers and 192 LDS-DMA pieces per round --
+// the issue cost of that ingest on the in-order wave streams is what bounds it.  Here the 16 members form
+// a 4 x 4 grid (jg, kg): member (jg, kg) keeps W_hh^T[units of group jg (128)][gate-gradient columns of the units of group
+// kg (3 x 128)] in registers (the same 196 KB) and needs only the K-SLICE kg of the gate gradients: 48 KiB per round, ONE
+// image, one barrier.  What it computes is a PARTIAL sum over its slice for the 128 units of group jg; contraction wave w
+// holds exactly the 32-unit quarter that member (jg, w) finishes, so it sends its accumulators straight to that member
+// (4 KiB, global memory / L2) and the gate waves of (jg, w) add the four quarters in a FIXED order.  Per member and round:
+// 48 KiB (image, shared by four readers) + 12 KiB (three quarters) in, 12 + 12 KiB out -- a third of the ingest, at the
+// price of a second hand-off per step.
+//
+//   iteration i = (ps - 1) * NR + r  (processing step ps >= 1, round r of 32 trials); slot s of the main loop:
+//     contraction waves : MFMAs of iteration s on image buffer s & 1, quarters out (own quarter: LDS ring slot s & 3)
+//     contraction waves : LDS-DMA of image s + 1 first, MFMAs of iteration s, quarters out, counted wait, flag of the quarters of
+//                         s - 1 (each wave for its own stores)
+//     gate waves        : flag of the gate gradients of s - 5, gate math of iteration s - 4 (exchange rows + outputs), requests
+//                         for the inputs of s - 2 (HBM: two slots ahead) and the quarters of s - 3 (L2: one slot ahead, behind
+//                         their flags), lookup of the flags of image s + 2.
+//   A gate gradient written in slot j + 4 is flagged in slot j + 5 and polled for image j + NR at the end of slot j + NR - 2:
+//   NR >= 8 rounds per cluster keep every first poll successful (cl_plan2).  Same protocol as above (sc1 loads, write-through
+//   or same-XCD write-back stores, counted vmcnt before the barrier, one lane's flag store after it); bounded spins.
+//   One step per launch (XPS_GRU_CLUSTER=steps, or a grid the device cannot hold at once): the same kernel twice per step --
+//   contraction only, then gate math only -- with every quarter passed through global memory: same sums, same bits.
+//
+// Operand image: [trial 32][plane 2][384] bf16, trials 1536 B apart WITHOUT padding; instead 16-byte chunk q of trial n sits
+// at chunk q ^ (n & 15) of its 256-byte window -- applied by the LDS-DMA source addresses, undone by the fragment reads --
+// which makes the b128 reads of every 16-lane group hit 16 distinct bank quads (MI355X_MICROARCH.md, LDS lane groups).
+// ------------------------------------------------------------------------------------------------------
+struct ClBwd2 {
+    const float* dy;
+    const float* dhn;
+    const float* y_ext;
+    const float* saved;
+    const float* w_hh_t[2];     // (H x 3H)
+    float* dgi;
+    float* dghn;
+    float* dh0;
+    float* keep;                // [ndir][B][H]  z * dh of the step processed before
+    void* xbuf;                 // [2 parity][ndir][Bp/32][4 slices][32 trials][2 planes][384] bf16
+    float* pbuf;                // [2 parity][cluster][NR][16 dst][4 src][1024] partial quarters
+    unsigned* flags;            // [cluster][NR][160]: 16 words "gate gradients of step v - 1 published" + pad, then [16 dst][4 src] "quarter of step v published"
+    unsigned* xcc;
+    unsigned* status;
+    unsigned* sticky;
+    unsigned xbuf_bytes, pbuf_bytes;
+    int T, B, H, ndir, Bp, Mc, NR, nblk;
+    int ps_total, handoff, do_ps0;
+    int c_begin, c_end, g_begin, g_end;     // iterations whose contraction / gate math this launch runs
+    int split_out;
+};
+
+constexpr int C2_IMG = 32 * 1536;           // one operand image
+#ifndef XPS_CL2_NT      // (non-temporal streams measured: 1106 vs 986 us per launch -- slower; not the default)
+#define CL2_STREAM_LOAD(ptr) (*reinterpret_cast<const f32x4*>(ptr))
+constexpr int CL2_AUX_STREAM = 0;
+#else
+#define CL2_STREAM_LOAD(ptr) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr))
+constexpr int CL2_AUX_STREAM = 2;           // raw buffer builtins: bit 1 = nt
+#endif
+constexpr int C2_LDS = 2 * C2_IMG + 4 * 4096 + 64;
+
+__device__ inline void cl_dma1(const unsigned char* gsrc, unsigned m0v) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(m0v));
+}
+
+// one piece, source = scalar base + 32-bit lane offset
+__device__ inline void cl_dma1s(const unsigned char* sbase, unsigned voff, unsigned m0v) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0v));
+}
+
+__global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ownq = smem + 2 * C2_IMG;           // ring of four own-quarter tiles (4 KiB each)
+    const unsigned lds0 = cl_lds_base(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const ClMap cm = cl_map(16);
+    const int dir = cm.cluster / p.nblk, blk = cm.cluster % p.nblk;
+    const int jg = cm.member >> 2, kg = cm.member & 3;
+    const int T = p.T, B = p.B, H = p.H, NR = p.NR;
+    const int ldy = p.ndir * H;
+    const int m_base = blk * p.Mc;
+    const int nclusters = p.ndir * p.nblk;
+    unsigned* myflags = p.flags + (long long)cm.cluster * NR * 160;
+    const bool fast = !p.handoff || cl_same_xcd(p.xcc + cm.cluster * 16, cm.member, 16, lane, wave == 4, p.status, p.sticky, reinterpret_cast<unsigned*>(smem));
+    const bool has_c = p.c_end > p.c_begin, has_g = p.g_end > p.g_begin;
+    auto valid_c = [&](int i) { return i >= p.c_begin && i < p.c_end; };
+    auto valid_g = [&](int i) { return i >= p.g_begin && i < p.g_end; };
+    int s_lo = 0x7fffffff, s_hi = -0x7fffffff;
+    if (has_c) { s_lo = p.c_begin - 1; s_hi = p.c_end - 1; }
+    if (has_g) { s_lo = min(s_lo, p.g_begin + 1); s_hi = max(s_hi, p.g_end + 2); }
+
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(p.pbuf, 0, p.pbuf_bytes, RSRC_FLAGS);
+    // byte offset of the quarter tile (parity, round, destination member, source column) in pbuf
+    auto p_off = [&](int ps_, int r_, int dst, int src) -> unsigned {
+        return (unsigned)((((((ps_ & 1) * nclusters + cm.cluster) * NR + r_) * 16 + dst) * 4 + src)) * 4096u;
+    };
+    // chunk (one slice of one round) of the gate-gradient exchange buffer
+    auto x_chunk = [&](int ps_src, int r_, int slice) -> unsigned {
+        return (unsigned)(((((ps_src & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r_) * 4 + slice)) * (unsigned)C2_IMG;
+    };
+
+    if (wave < 4) {
+        // ---------------- contraction waves ----------------
+        // Besides the MFMAs they own every LDS-DMA of the kernel (12 pieces per wave and slot, issued FIRST: the MFMAs that
+        // follow cover the landing) and their own quarter hand-off: stores, a counted wait one slot later, then ONE lane's flag
+        // per wave (each storing wave signals for itself: MI355X_MICROARCH.md, "Valid forms", third table row).
+        if (p.do_ps0) { __syncthreads(); }
+        if (s_lo > s_hi) return;
+        // LDS-DMA of one image: a LINEAR copy of the 48-KiB chunk (the bank swizzle is applied by the WRITERS of the gate gradients:
+        // a piece whose lanes fetch permuted 16-byte chunks is split into per-lane requests and blocks its issuer ~650 cycles
+        // instead of ~80); wave w moves bytes [12 w, 12 w + 12) KiB in three groups of four 1-KiB pieces
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+        auto dma_image = [&](int i) {
+            const int ps = i / NR + 1, r = i % NR;
+            const unsigned char* src = xb + x_chunk(ps - 1, r, kg) + wave * 12288 + lane * 16;
+            const unsigned dst = lds0 + (unsigned)((i & 1) * C2_IMG) + (unsigned)(wave * 12288);
+#pragma unroll
+            for (int g4 = 0; g4 < 3; ++g4) cl_dma4(src + g4 * 4096, dst + g4 * 4096, dst + g4 * 4096, dst + g4 * 4096, dst + g4 * 4096);
+        };
+        if (has_c && p.handoff) __syncthreads();           // (wave 4's poll for the first image)
+        if (has_c) {
+            dma_image(p.c_begin);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                   // image of the first iteration has landed
+        const float* __restrict__ WT = p.w_hh_t[dir];
+        bf16x8 wh[2][12], wl[2][12];
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut) {
+            const int jr = jg * 128 + wave * 32 + ut * 16 + n;
+            const bool rlive = has_c && jr < H;                // (a gate-only launch contracts nothing: no weight traffic)
+            const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const int ku = kg * 128 + (c & 3) * 32 + 8 * kq;
+                const float* src = wrow + (c >> 2) * H + ku;
+                const bool ok0 = rlive && ku + 3 < H, ok1 = rlive && ku + 7 < H;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(ok0 ? src : WT);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(ok1 ? src + 4 : WT);
+                if (!ok0) v0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!ok1) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, b;
+                    bf_split(v0[e], a, b); wh[ut][c][e] = a; wl[ut][c][e] = b;
+                    bf_split(v1[e], a, b); wh[ut][c][4 + e] = a; wl[ut][c][4 + e] = b;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the weight loads: the counted waits below assume an empty queue)
+        const bool own_lds = p.handoff && wave == kg;      // this wave's quarter is the member's own: through LDS
+        unsigned frag_lane[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) frag_lane[m] = (unsigned)(n * 1536 + ((((m ^ (n >> 2)) << 2) | (kq ^ (n & 3))) << 4));
+#ifdef XPS_CL_STAMP
+        unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sbA = 0, sbB = 0, s_bar = 0, s_work = 0, s_drain = 0, s_dma = 0, s_mma = 0;
+        CL_STAMP(sb2)
+#endif
+        for (int s = s_lo; s <= s_hi; ++s) {
+            // (1) the image of the next iteration (its flags were polled by wave 4 before the last barrier)
+            const bool dma_now = s + 1 != p.c_begin && valid_c(s + 1);
+            if (dma_now) dma_image(s + 1);
+            CL_FENCE();
+            // (2) the quarters stored at the end of the last slot are in memory by now (they had the barrier and the DMA issue):
+            //     this wave flags them for their reader before its MFMAs, not after
+            if (p.handoff && !own_lds && valid_c(s - 1)) {
+                if (dma_now) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const int i = s - 1;
+                    __hip_atomic_store(myflags + (i % NR) * 160 + 64 + (jg * 4 + wave) * 4 + kg, (unsigned)(i / NR + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            CL_FENCE();
+            CL_STAMP(sbA)
+            int nst = 0;
+            if (valid_c(s)) {
+                const int ps = s / NR + 1, r = s % NR;
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[ut][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // 24 steps (trial tile, 32-wide k chunk); the fragments of step i + 2 are requested before the MFMAs of step i (a
+                // ring of three, pinned with scheduling barriers: left alone the scheduler issues every read right in front of
+                // its six MFMAs and exposes the LDS latency 24 times per slot: 7800 instead of ~2600 cycles).  Addresses: chunk
+                // (4 c + kq) ^ n = 16 (c >> 2) + (4 ((c & 3) ^ (n >> 2)) | (kq ^ (n & 3))): four lane offsets (by c & 3), the
+                // rest is an immediate.
+                unsigned fa[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) fa[m] = frag_lane[m] + (unsigned)((s & 1) * C2_IMG);
+                bf16x8 fh[3], fl[3];
+                auto frag = [&](int i, bf16x8& h8, bf16x8& l8) {
+                    const unsigned char* rp = smem + fa[(i % 12) & 3] + ((i / 12) * 16 * 1536 + ((i % 12) >> 2) * 256);
+                    h8 = *reinterpret_cast<const bf16x8*>(rp);
+                    l8 = *reinterpret_cast<const bf16x8*>(rp + 768);
+                };
+                frag(0, fh[0], fl[0]);
+                frag(1, fh[1], fl[1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    const int tt = i / 12, c = i % 12;
+                    if (i + 2 < 24) frag(i + 2, fh[(i + 2) % 3], fl[(i + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 bh = fh[i % 3], bl = fl[i % 3];
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut) {
+                        acc[ut][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ut][c], bh, acc[ut][tt], 0, 0, 0);
+                        acc[ut][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ut][c], bl, acc[ut][tt], 0, 0, 0);
+                        acc[ut][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ut][c], bh, acc[ut][tt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                CL_STAMP(sbB)
+                CL_ACC(s_mma, sbA, sbB)
+                if (own_lds) {
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+                            *reinterpret_cast<f32x4*>(ownq + (s & 3) * 4096 + ((ut * 2 + tt) * 64 + lane) * 16) = acc[ut][tt];
+                } else {
+                    const unsigned base = p_off(ps, r, jg * 4 + wave, kg) + (unsigned)lane * 16u;
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ut][tt]), pr, base + (unsigned)(ut * 2 + tt) * 1024u, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ut][tt]), pr, base + (unsigned)(ut * 2 + tt) * 1024u, 0, AUX_SC1);
+                        }
+                    nst = 4;
+                }
+            }
+            CL_FENCE();
+            CL_STAMP(sb3)
+            // (3) everything but this slot's four stores is complete: the image of the next iteration has landed
+            if (nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CL_STAMP(sb0)
+            __syncthreads();
+            CL_STAMP(sb1)
+            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb0) CL_ACC(s_dma, sb2, sbA)
+#ifdef XPS_CL_STAMP
+            sb2 = sb1;
+#endif
+        }
+#ifdef XPS_CL_STAMP
+        if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 4] = s_dma; g_clstamp[wid * 8 + 5] = s_mma; }
+#endif
+        return;
+    }
+
+    // ---------------- gate waves ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int hw = wave - 4;
+    const int hut = hw >> 1, te = hw & 1;
+    const int uo = kg * 32 + hut * 16 + 4 * kq;           // this lane's four units inside group jg
+    const int ju = jg * 128 + uo;
+    const bool ulive = ju < H;
+    const int juc = ulive ? ju : 0;
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgi, 0, (unsigned)((long long)p.ndir * T * B * 3 * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(p.dghn, 0, (unsigned)((long long)p.ndir * T * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
+    const bool has_dy = p.dy != nullptr;
+
+    struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
+    auto epi_load = [&](int ps, int r, EpiIn& in) -> int {
+        const int s_ = T - 1 - ps;
+        const int t = (dir == 0) ? s_ : T - 1 - s_;
+        const int slot_prev = (dir == 0) ? t : t + 2;
+        const int b = m_base + 32 * r + 16 * te + n;
+        const int bc = b < B ? b : B - 1;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        int nload = 0;
+        in.keep = (u32x4){0u, 0u, 0u, 0u};
+#ifdef XPS_CL2_ABL_NOLOAD
+        in.dy = z4 + 0.01f; in.rg = z4 + 0.5f; in.zg = z4 + 0.4f; in.ng = z4 + 0.1f; in.q = z4 + 0.2f; in.hp = z4 + 0.3f;
+        (void)slot_prev; (void)bc;
+        return 0;
+#endif
+        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1); ++nload; }
+        else if (p.dhn) { in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc)); ++nload; }
+        if (ps < T) {
+            in.dy = z4;
+            // read-once streams: non-temporal, so that they do not push the exchange lines (re-read a few slots after they were
+            // written) out of the XCD's 4-MiB L2 -- an LDS-DMA piece that misses L2 blocks its issuer ~650 instead of ~100 cycles
+            if (has_dy) { in.dy = CL2_STREAM_LOAD(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc); ++nload; }
+            const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+            in.rg = CL2_STREAM_LOAD(sv);
+            in.zg = CL2_STREAM_LOAD(sv + H);
+            in.ng = CL2_STREAM_LOAD(sv + 2 * H);
+            in.q = CL2_STREAM_LOAD(sv + 3 * H);
+            in.hp = CL2_STREAM_LOAD(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
+            nload += 5;
+        } else {
+            in.dy = z4; in.rg = z4; in.zg = z4; in.ng = z4; in.q = z4; in.hp = z4;
+        }
+        return nload;
+    };
+    // gate gradients of processing step ps, round r for this lane's trial and four units; acc = dgh_{ps-1} W_hh (own units).
+    // Stores: the exchange rows first, then the outputs (always issued: dead lanes are dropped by the range check).
+    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc, auto&& before_stores) {
+        const int s_ = T - 1 - ps;
+        const int t = (dir == 0) ? s_ : T - 1 - s_;
+        const int b = m_base + 32 * r + 16 * te + n;
+        bool live = b < B && ulive;
+        f32x4 carry = __builtin_bit_cast(f32x4, in.keep);
+        if (ps > 0) carry += acc;
+        if (ps == T) {
+            before_stores();
+            CL_FENCE();
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, carry), hr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+            return;
+        }
+        f32x4 dar, daz, dan, danr, keep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dh = in.dy[i] + carry[i];
+            const float r_ = in.rg[i], z_ = in.zg[i], n_ = in.ng[i];
+            const float dn = dh * (1.f - z_);
+            const float dz = dh * (in.hp[i] - n_);
+            const float da = dn * (1.f - n_ * n_);
+            daz[i] = live ? dz * z_ * (1.f - z_) : 0.f;
+            dar[i] = live ? da * in.q[i] * r_ * (1.f - r_) : 0.f;
+            dan[i] = da;
+            danr[i] = live ? da * r_ : 0.f;
+            keep[i] = dh * z_;
+        }
+        // (the next iteration's quarter requests go out between the arithmetic and this iteration's eleven stores)
+        CL_FENCE();
+        before_stores();
+        CL_FENCE();
+        if (ps + 1 < p.ps_total) {                      // someone will contract these gradients: slice jg of round r
+            // row of trial (16 te + n), plane-row byte L = 2 (128 g + uo) -> 16-byte chunk (L >> 4) ^ n of its 256-byte window
+            // (the operand image's bank swizzle, see the kernel header; n = trial & 15), byte L & 15 inside the chunk
+            const unsigned base = x_chunk(ps, r, jg) + (unsigned)(16 * te + n) * 1536u;
+            const unsigned Lq = (unsigned)uo >> 3, Lw = ((unsigned)uo & 4u) << 1;
+            const f32x4* gsrc[3] = {&dar, &daz, &danr};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                bf16x4 sh, sl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split((*gsrc[g])[i], a, c); sh[i] = a; sl[i] = c; }
+                const unsigned o = base + ((((unsigned)(16 * g) + Lq) ^ (unsigned)n) << 4) + Lw;
+                if (fast) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, AUX_SC1);
+                }
+            }
+        }
+        CL_FENCE();
+#ifdef XPS_CL2_ABL_NOSTORE
+        const unsigned go = (b == -12345) ? 0u : CL_OOB;      // every output store dropped by the range check
+        live = false;
+#else
+        const unsigned go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
+#endif
+        if (p.split_out) { dar = split4_pack(dar); daz = split4_pack(daz); dan = split4_pack(dan); danr = split4_pack(danr); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dar), gr, go, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+    };
+
+    if (p.do_ps0) {
+        // first processing step: no contraction, the running gradient starts from dhn (or zero)
+        for (int r = 0; r < NR; ++r) {
+            EpiIn in;
+            epi_load(0, r, in);
+            epilogue(0, r, in, (f32x4){0.f, 0.f, 0.f, 0.f}, [] {});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int r = 0; p.handoff && r < NR; r += 64)          // (every gate wave for its own stores)
+            if (r + lane < NR) __hip_atomic_store(myflags + (r + lane) * 160 + cm.member * 4 + hw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    if (s_lo > s_hi) return;
+
+    // polls (wave 4).  Flags of a round r: words [0, 16) "gate gradients of step v - 1 published" per member (one lane's store
+    // behind the workgroup's counted waits and barrier); words [32 + 4 dst, 32 + 4 dst + 4) "quarter of step v for member dst
+    // from column src published" (the storing contraction wave's own flag).  The image of iteration i needs the gate gradients
+    // of step ps - 1 from the members (kg, 0..3); the gate math of iteration i the quarters of step ps from the columns c != kg.
+    // Both are looked up at the START of a slot (the loads are in flight during the gate math) and, on a miss, polled at its end.
+    auto flag_image = [&](int i) -> const unsigned* { return myflags + (i % NR) * 160 + kg * 16; };
+    auto flag_quarters = [&](int i) -> const unsigned* { return myflags + (i % NR) * 160 + 64 + cm.member * 4; };
+    // (skip_own: the four quarter flags of this member, its own column excluded; else: the 16 gate-gradient flags -- four gate
+    //  waves of each of the four members that write the slice)
+    auto peek = [&](const unsigned* f, bool skip_own) -> unsigned {
+        unsigned v = 0xffffffffu;
+        if (skip_own ? (lane < 4 && lane != kg) : lane < 16) v = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto wait_flags = [&](const unsigned* f, bool skip_own, unsigned need, unsigned first, int stat) {
+        if (__all(first >= need)) return;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool ok = false;
+        for (;;) {
+            const unsigned v = peek(f, skip_own);
+            if (__all(v >= need)) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) break;
+        }
+        if (lane == 0) {
+            const unsigned dt = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);
+            if (!ok) { __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p.sticky) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            __hip_atomic_fetch_add(p.status + stat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.status + stat + 1, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    // the image of the first iteration: its flags (persistent form), then the contraction waves' LDS-DMA; barriers mirror theirs
+    if (has_c && p.handoff) {
+        if (wave == 4) wait_flags(flag_image(p.c_begin), false, (unsigned)(p.c_begin / NR + 1), 0u, 1);
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // Gate-wave slot s (see the header): the inputs of a gate math travel two slots (saved gates / dy / h_prev / running gradient:
+    // HBM) and one slot (quarters: L2) ahead of it, in two register sets that alternate by slot parity (the loop body is
+    // instantiated per parity: no copies, no dynamic register index).  Every gate wave looks its own quarter flags up at the
+    // start of a slot -- published a whole slot earlier, so the lookup hits unless the cluster is badly skewed -- and requests the
+    // quarters once it has matched (the polling wave loads behind its own matched poll: no barrier needed).
+    EpiIn ein[2];
+    f32x4 pqs[2][4];                                    // quarters: requested into set `par` in one slot, summed from it in the next
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pqs[0][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; pqs[1][c] = pqs[0][c]; }
+#ifdef XPS_CL_STAMP
+    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, sbA = 0, sbB = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0, s_math = 0, s_q = 0;
+    CL_STAMP(sb2)
+#endif
+    int prev_younger = 0;
+    auto slot_body = [&](int s, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        // (1) flag: this wave's exchange rows of iteration s - 4 (stored in slot s - 1: the oldest operations still counted; a
+        //     whole barrier later they are complete and the wait returns at once -- nothing waits for store completion BEFORE a
+        //     barrier); lookups: image of iteration s + 2 (wave 4), quarters of iteration s - 2 (every gate wave; flagged by
+        //     their contraction waves early in slot s - 1)
+        unsigned la_img = 0xffffffffu, la_q = 0xffffffffu;
+        if (p.handoff) {
+            if (valid_g(s - 4)) {
+                const int i = s - 4, ps = i / NR + 1;
+                if (ps + 1 < p.ps_total) {
+                    cl_wait_vmcnt(prev_younger);
+                    if (lane == 0) __hip_atomic_store(myflags + (i % NR) * 160 + cm.member * 4 + hw, (unsigned)(ps + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (wave == 4 && valid_c(s + 2)) la_img = peek(flag_image(s + 2), false);
+            if (valid_g(s - 2)) la_q = peek(flag_quarters(s - 2), true);
+        }
+        CL_FENCE();
+        // (3) quarter requests of iteration s - 2 (own one: LDS; when every step is a launch: all four from global memory), issued
+        //     from inside the gate math below, between its arithmetic and its stores
+        int nq = 0;
+        auto request_quarters = [&]() {
+            if (!valid_g(s - 2)) return;
+            const int i = s - 2, ps = i / NR + 1, r = i % NR;
+            if (p.handoff) wait_flags(flag_quarters(i), true, (unsigned)ps, la_q, 6);
+            const unsigned tile = (unsigned)(((hut * 2 + te) * 64 + lane) * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (p.handoff && c == kg) {
+                    pqs[par][c] = *reinterpret_cast<const f32x4*>(ownq + (i & 3) * 4096 + tile);
+                } else {
+                    pqs[par][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, p_off(ps, r, cm.member, c) + tile, 0, AUX_SC1));
+                    ++nq;
+                }
+            }
+        };
+        // (2) gate math of iteration s - 3 (quarters requested in slot s - 1, the rest in slot s - 2)
+        int younger = 0;
+        if (valid_g(s - 3)) {
+            const int i = s - 3, ps = i / NR + 1;
+            const f32x4 a = ((pqs[1 - par][0] + pqs[1 - par][1]) + pqs[1 - par][2]) + pqs[1 - par][3];
+            epilogue(ps, i % NR, ein[par], a, request_quarters);
+            younger += ps == T ? 1 : 5;                      // the stores behind the exchange rows
+        } else {
+            request_quarters();
+        }
+        CL_FENCE();
+        CL_STAMP(sbA)
+        CL_ACC(s_math, sb2, sbA)
+        // (4) the inputs of the gate math of iteration s - 1 (two slots ahead; into the set this slot's gate math has released)
+        if (valid_g(s - 1)) younger += epi_load((s - 1) / NR + 1, (s - 1) % NR, ein[par]);
+        CL_FENCE();
+        CL_STAMP(sbB)
+        CL_ACC(s_q, sbA, sbB)
+        CL_STAMP(sb3)
+        // nothing to drain here: the exchange rows are flagged in the next slot (see (1)); `younger` operations follow them.  NB the
+        // quarter requests were issued BEFORE the exchange rows: they are older and complete with them
+        prev_younger = younger;
+        CL_STAMP(sb4)
+        // (5) the image of iteration s + 2 is DMA'd in the next slot: its flags must have matched before the barrier
+        if (p.handoff && wave == 4 && valid_c(s + 2)) wait_flags(flag_image(s + 2), false, (unsigned)((s + 2) / NR + 1), la_img, 1);
+        CL_STAMP(sb0)
+        __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb4) CL_ACC(s_poll, sb4, sb0)
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
+    };
+    for (int s = s_lo; s <= s_hi; s += 2) {
+        slot_body(s, std::integral_constant<int, 0>{});
+        if (s + 1 <= s_hi) slot_body(s + 1, std::integral_constant<int, 1>{});
+    }
+#ifdef XPS_CL_STAMP
+    if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; g_clstamp[wid * 8 + 4] = s_math; g_clstamp[wid * 8 + 5] = s_q; }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
 struct ClPlan {
@@ -1081,6 +1612,39 @@ ClPlan cl_plan(int B, int H, int ndir) {
     return pl;
 }
 
+// 2-D cluster BPTT (gru_cluster2_bwd_kernel): bf16x3 mode, 384 < H <= 512, clusters of 16 = 4 x 4, >= 8 rounds of 32 trials
+// per cluster (the two hand-offs of a step span 7 slots of the round pipeline).  XPS_GRU_CL2=0: the 1-D kernel everywhere.
+struct ClPlan2 {
+    bool ok;
+    int nblk, Mc, NR, Bp, grid;
+    size_t flags_bytes, keep_bytes, xbuf, pbuf;
+};
+ClPlan2 cl_plan2(int B, int H, int ndir) {
+    ClPlan2 pl;
+    memset(&pl, 0, sizeof(pl));
+    static const bool enabled = [] { const char* e = getenv("XPS_GRU_CL2"); return !(e && e[0] == '0'); }();
+    if (!enabled || cl_mode() == 0 || H <= 384 || H > 512 || (H % 4) != 0 || B < 128) return pl;
+    const int max_blk = cl_num_cus() / (16 * ndir);
+    if (max_blk < 1) return pl;
+    int nblk = B / 256;
+    if (nblk > max_blk) nblk = max_blk;
+    if (nblk < 1) nblk = 1;
+    pl.nblk = nblk;
+    const int per = (B + nblk - 1) / nblk;
+    pl.Mc = ((per + 31) / 32) * 32;
+    if (pl.Mc < 256) pl.Mc = 256;
+    pl.NR = pl.Mc / 32;
+    pl.Bp = pl.nblk * pl.Mc;
+    pl.grid = ndir * pl.nblk * 16;
+    // header: flags [cluster][NR][160], XCC table [cluster][16], padding, status block (last 256 B); zeroed before every launch
+    pl.flags_bytes = (((size_t)ndir * pl.nblk * (pl.NR * 160 + 16) * 4 + 256 + 255) / 256) * 256;
+    pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
+    pl.xbuf = (size_t)2 * ndir * (pl.Bp / 32) * 4 * C2_IMG;
+    pl.pbuf = (size_t)2 * ndir * pl.nblk * pl.NR * 64 * 4096;
+    pl.ok = pl.xbuf < ((size_t)1 << 31) && pl.pbuf < ((size_t)1 << 32);
+    return pl;
+}
+
 template <typename K>
 bool cl_set_lds(K kernel, int bytes) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
@@ -1128,7 +1692,12 @@ size_t xps_internal_gru_cluster_fwd_workspace(int B, int H, int ndir) {
 
 size_t xps_internal_gru_cluster_bwd_workspace(int B, int H, int ndir) {
     const ClPlan pl = cl_plan(B, H, ndir);
-    return pl.ok ? pl.flags_bytes + pl.keep_bytes + pl.xbuf_bwd : 0;
+    if (!pl.ok) return 0;
+    size_t n = pl.flags_bytes + pl.keep_bytes + pl.xbuf_bwd;
+    // (both BPTT kernels' needs, whatever the precision mode is when the launch comes: the mode is a run-time switch)
+    const ClPlan2 p2 = cl_plan2(B, H, ndir);
+    if (p2.ok) { const size_t n2 = p2.flags_bytes + p2.keep_bytes + p2.xbuf + p2.pbuf; if (n2 > n) n = n2; }
+    return n;
 }
 
 size_t xps_internal_gru_cluster_status_offset(int B, int H, int ndir) {
@@ -1197,6 +1766,53 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     const ClPlan pl = cl_plan(B, H, ndir);
     if (!pl.ok) { xps_set_error("gru cluster backward: unsupported shape"); return XPS_E_INVALID; }
     const bool bf = xps_internal_gemm_mode() == 1;
+    if (split_out && !bf) { xps_set_error("gru cluster backward: XPS_FMT_SPLIT4 outputs exist in bf16x3 mode only"); return XPS_E_INVALID; }
+    const ClPlan2 p2 = cl_plan2(B, H, ndir);
+    if (bf && p2.ok) {
+        ClBwd2 q;
+        q.dy = dy; q.dhn = dhn; q.y_ext = y_ext; q.saved = saved; q.dgi = dgi; q.dghn = dghn; q.dh0 = dh0;
+        q.split_out = split_out;
+        for (int d = 0; d < 2; ++d) q.w_hh_t[d] = w_hh_t[d < ndir ? d : 0];
+        if (!cl_aligned16(dy) || !cl_aligned16(dhn) || !cl_aligned16(y_ext) || !cl_aligned16(saved) || !cl_aligned16(q.w_hh_t[0]) ||
+            !cl_aligned16(q.w_hh_t[1]) || !cl_aligned16(dgi) || !cl_aligned16(dghn) || !cl_aligned16(dh0) || !cl_aligned16(workspace)) {
+            xps_set_error("gru cluster backward: operands must be 16-byte aligned");
+            return XPS_E_INVALID;
+        }
+        unsigned char* ws = (unsigned char*)workspace;
+        q.flags = (unsigned*)ws;
+        q.xcc = q.flags + (size_t)ndir * p2.nblk * p2.NR * 160;
+        q.status = (unsigned*)(ws + p2.flags_bytes - 256);
+        q.sticky = cl_sticky();
+        q.keep = (float*)(ws + p2.flags_bytes);
+        q.xbuf = ws + p2.flags_bytes + p2.keep_bytes;
+        q.pbuf = (float*)(ws + p2.flags_bytes + p2.keep_bytes + p2.xbuf);
+        q.xbuf_bytes = (unsigned)p2.xbuf;
+        q.pbuf_bytes = (unsigned)p2.pbuf;
+        q.T = T; q.B = B; q.H = H; q.ndir = ndir; q.Bp = p2.Bp; q.Mc = p2.Mc; q.NR = p2.NR; q.nblk = p2.nblk;
+        if (hipMemsetAsync(ws, 0, p2.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster backward: memset failed"); return XPS_E_HIP; }
+        const int ps_total = T + (dh0 ? 1 : 0);
+        q.ps_total = ps_total;
+        if (!cl_set_lds(gru_cluster2_bwd_kernel, C2_LDS)) { xps_set_error("gru cluster backward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
+        const int n_it = (ps_total - 1) * p2.NR;
+        const bool persistent = cl_mode() == 2 && p2.grid <= cl_resident(gru_cluster2_bwd_kernel, C2_LDS, 1, 1);
+        if (persistent) {
+            q.handoff = 1; q.do_ps0 = 1; q.c_begin = 0; q.c_end = n_it; q.g_begin = 0; q.g_end = n_it;
+            hipLaunchKernelGGL(gru_cluster2_bwd_kernel, dim3(p2.grid), dim3(512), C2_LDS, st, q);
+        } else {
+            // one step per launch: the gate pass of step 0, then per step a contraction launch and a gate launch
+            q.handoff = 0; q.do_ps0 = 1; q.c_begin = q.c_end = q.g_begin = q.g_end = 0;
+            hipLaunchKernelGGL(gru_cluster2_bwd_kernel, dim3(p2.grid), dim3(512), C2_LDS, st, q);
+            q.do_ps0 = 0;
+            for (int ps = 1; ps < ps_total; ++ps) {
+                q.c_begin = (ps - 1) * p2.NR; q.c_end = ps * p2.NR; q.g_begin = q.g_end = 0;
+                hipLaunchKernelGGL(gru_cluster2_bwd_kernel, dim3(p2.grid), dim3(512), C2_LDS, st, q);
+                q.g_begin = q.c_begin; q.g_end = q.c_end; q.c_begin = q.c_end = 0;
+                hipLaunchKernelGGL(gru_cluster2_bwd_kernel, dim3(p2.grid), dim3(512), C2_LDS, st, q);
+            }
+        }
+        XPS_CHECK_LAUNCH();
+        return XPS_OK;
+    }
     ClBwd p;
     p.dy = dy; p.dhn = dhn; p.y_ext = y_ext; p.saved = saved; p.dgi = dgi; p.dghn = dghn; p.dh0 = dh0;
     if (split_out && !bf) { xps_set_error("gru cluster backward: XPS_FMT_SPLIT4 outputs exist in bf16x3 mode only"); return XPS_E_INVALID; }
@@ -1243,6 +1859,14 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     if (!ok) { xps_set_error("gru cluster backward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
     XPS_CHECK_LAUNCH();
     return XPS_OK;
+}
+
+// diagnostics (tools/): byte offset of the status block in the BPTT workspace of the kernel the current mode selects
+extern "C" long long xps_debug_gru_bwd_status_offset(int B, int H, int ndir) {
+    const ClPlan2 p2 = cl_plan2(B, H, ndir);
+    if (xps_internal_gemm_mode() == 1 && p2.ok) return (long long)p2.flags_bytes - 256;
+    const ClPlan pl = cl_plan(B, H, ndir);
+    return pl.ok ? (long long)pl.flags_bytes - 256 : -1;
 }
 
 #ifdef XPS_CL_STAMP

@@ -29,6 +29,6 @@ pmc gru_f FETCH_SIZE BWD=1 tools/run_gru_fwd.py && pmc gru_w WRITE_SIZE BWD=1 to
 pmc tn_f FETCH_SIZE X=1 tools/run_wgrad_group.py && pmc tn_w WRITE_SIZE X=1 tools/run_wgrad_group.py &&
 python3 $R/tools/pmc_traffic.py $O/pmc_traffic.json \
   gru_cluster_fwd_kernel_bf16x3=gru_cluster_fwd_kernel:1342177280:/tmp/c_gru_f.csv:/tmp/c_gru_w.csv \
-  gru_cluster_bwd_kernel_bf16x3=gru_cluster_bwd_kernel:1677721600:/tmp/c_gru_f.csv:/tmp/c_gru_w.csv \
+  gru_cluster_bwd_kernel_bf16x3=_bwd_kernel:1677721600:/tmp/c_gru_f.csv:/tmp/c_gru_w.csv \
   gemm_tn_grouped_kernel_bf16x3=gemm_tn_grouped_kernel:252844032:/tmp/c_tn_f.csv:/tmp/c_tn_w.csv:+gemm_tn_grouped_reduce > $O/pmc.log 2>&1
 tail -3 $O/h512_serial_summary.md; tail -1 $O/cfg2_step_timeline.txt; tail -1 $O/h512_step_timeline.txt; tail -25 $O/pmc.log
