@@ -390,7 +390,7 @@ def alignment_record(dev):
     cross-covariance + the replicated eigensolve; the exchanges -- 8 x 13 MB of views, 8 MB of block rows -- not included)."""
     import numpy as np
     from cross_patient_speech_decoding_amd import alignment as A
-    from cross_patient_speech_decoding_amd.alignment import AlignMCCA as M
+    from cross_patient_speech_decoding_amd.alignment.AlignMCCA import _gevp
     from cross_patient_speech_decoding_amd.alignment import _linalg as LA
     from cross_patient_speech_decoding_amd.alignment.alignment_utils import _group_conditions_device
     from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
@@ -431,7 +431,7 @@ def alignment_record(dev):
     t_share = med(rank_share, n=3)
     G = torch.cat([LA.xcov(avgs_all[i], Zc, mean[128 * i:128 * (i + 1)].contiguous(), mean) for i in range(P)], dim=0).cpu().numpy()
     offs = np.arange(P + 1) * 128
-    t_tail = med(lambda: M._gevp(G, offs, 30, 0.5), n=3)
+    t_tail = med(lambda: _gevp(G, offs, 30, 0.5), n=3)
     by = Xd[0].numel() * 4
     return {'workload': 'north-star patients: 8 x (2048 trials x 200 x 128 ch fp32 = 210 MB), inputs resident in HBM',
             'pca_fit': {'ms': round(t_pca * 1e3, 2), 'fits_per_s': round(1 / t_pca, 1), 'input_GB_per_s': round(by / t_pca / 1e9, 1)},

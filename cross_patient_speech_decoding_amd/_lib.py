@@ -69,6 +69,8 @@ SIGNATURES = {
     'xps_gru_seq_fwd_f32_workspace': (_sz, [_i, _i, _i, _i]),
     'xps_gru_seq_status_offset': (C.c_longlong, [_i, _i, _i, _i]),
     'xps_gru_set_status_word': (_i, [_vp]),
+    'xps_set_gru_bptt_grid': (_i, [_i]),
+    'xps_get_gru_bptt_grid': (_i, []),
     'xps_set_gru_cluster_mode': (_i, [_i]),
     'xps_get_gru_cluster_mode': (_i, []),
     'xps_gru_seq_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

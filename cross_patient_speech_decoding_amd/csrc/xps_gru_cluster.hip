@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
     };
 
-    if (wave >= 4) {
+    if (wave < 4) {
         const unsigned char* src = dma_src(p.s_begin, 0);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) dma_group(src, it_begin & 1, g4);
@@ -345,34 +345,50 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             w.load(seg, rlive, kq, H - kbase, W);
         }
         CL_STAMP(sb2)
+        int s_nx = p.s_begin, r_nx = 0;                 // (step, round) of round it + 1
         for (int it = it_begin; it < it_end; ++it) {
             const unsigned char* tb = smem + (it & 1) * TILE;
+            // the operand image of round it + 1, first thing (its flags were polled by wave 4 two rounds ago): this wave's 16 pieces;
+            // the MFMAs below cover their landing, the counted wait before the barrier finds them complete
+            if (++r_nx == NR) { r_nx = 0; ++s_nx; }
+            if (it + 1 < it_end) {
+                const unsigned char* src = dma_src(s_nx, r_nx);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) dma_group(src, (it + 1) & 1, g4);
+            }
+            CL_FENCE();
             f32x4 acc[2][3];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[tt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (BF) {
-                // 16 steps (tile, chunk); the fragments of step i + 1 are requested before the MFMAs of step i
+                // 16 steps (tile, chunk); the fragments of step i + 2 are requested before the MFMAs of step i (a ring of three,
+                // pinned with scheduling barriers: left alone the scheduler issues the reads of two steps right in front of
+                // their 18 MFMAs and exposes the LDS latency eight times per round)
                 const unsigned char* rp0 = tb + n * TS + (kbase + 8 * kq) * 2;
-                bf16x8 bh[2], bl[2];
-                bh[0] = *reinterpret_cast<const bf16x8*>(rp0);
-                bl[0] = *reinterpret_cast<const bf16x8*>(rp0 + PS);
+                bf16x8 bh[3], bl[3];
+                auto frag = [&](int i, bf16x8& h8, bf16x8& l8) {
+                    const unsigned char* rp = rp0 + (i >> 3) * 16 * TS + (i & 7) * 64;
+                    h8 = *reinterpret_cast<const bf16x8*>(rp);
+                    l8 = *reinterpret_cast<const bf16x8*>(rp + PS);
+                };
+                frag(0, bh[0], bl[0]);
+                frag(1, bh[1], bl[1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int tt = i >> 3, c = i & 7;
-                    if (i + 1 < 16) {
-                        const unsigned char* rp = rp0 + ((i + 1) >> 3) * 16 * TS + ((i + 1) & 7) * 64;
-                        bh[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rp);
-                        bl[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rp + PS);
-                    }
-                    const bf16x8 h8 = bh[i & 1], l8 = bl[i & 1];
+                    if (i + 2 < 16) frag(i + 2, bh[(i + 2) % 3], bl[(i + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 h8 = bh[i % 3], l8 = bl[i % 3];
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[g][c], h8, acc[tt][g], 0, 0, 0);
                         acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], l8, acc[tt][g], 0, 0, 0);
                         acc[tt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[g][c], h8, acc[tt][g], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
@@ -401,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
                 for (int g = 0; g < 3; ++g)
                     *reinterpret_cast<f32x4*>(xacc + ((wave * 2 + tt) * 3 + g) * 1024 + lane * 16) = acc[tt][g];
             CL_STAMP(sb3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next image have landed
             CL_STAMP(sb0)
             __syncthreads();
             CL_STAMP(sb1)
@@ -539,16 +556,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         unsigned fl = 0xffffffffu;
         if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r_n2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         CL_FENCE();
-        if (it + 1 < it_end) {                              // this wave's 16 pieces of round it + 1 (older than the exchange stores below)
-            int rn = r_pv + 2, sn = s_pv;
-            if (rn >= NR) { rn -= NR; ++sn; }
-            const unsigned char* src = dma_src(sn, rn);
-            // (half of them issued by the contraction waves between their MFMAs instead: 627 -> 635 us per launch; the round is
-            //  not paced by the slower role but by the spread of all eight waves at the barrier)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) dma_group(src, (it + 1) & 1, g4);
-        }
-        CL_FENCE();
+        // (the LDS-DMA of round it + 1 is issued by the contraction waves, first thing in their round: here the pieces sat in
+        //  front of the gate math, whose compiler-placed waits cannot see them and waited for their landing every round)
         int younger = 0;                                    // operations issued after the exchange stores (see cl_wait_vmcnt)
         if (it > it_begin) {
             take_products(it - it_begin);
@@ -999,35 +1008,38 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward, TWO-DIMENSIONAL cluster (bf16x3 mode, 384 < H <= 512): the default BPTT kernel of the north-star shape.
+// backward, TWO-DIMENSIONAL cluster (bf16x3 mode, 384 < H <= 512): opt-in alternative to the kernel above (see cl_plan2).
 //
 // The kernel above gives every member ALL 3H gate-gradient columns of its trials: 192 KiB of operand image per round of 32
-// trials through the vector-memory path of every CU (1.5 MB per step), three barriers and 192 LDS-DMA pieces per round --
-// the issue cost of that ingest on the in-order wave streams is what bounds it.  Here the 16 members form
-// a 4 x 4 grid (jg, kg): member (jg, kg) keeps W_hh^T[units of group jg (128)][gate-gradient columns of the units of group
-// kg (3 x 128)] in registers (the same 196 KB) and needs only the K-SLICE kg of the gate gradients: 48 KiB per round, ONE
-// image, one barrier.  What it computes is a PARTIAL sum over its slice for the 128 units of group jg; contraction wave w
-// holds exactly the 32-unit quarter that member (jg, w) finishes, so it sends its accumulators straight to that member
-// (4 KiB, global memory / L2) and the gate waves of (jg, w) add the four quarters in a FIXED order.  Per member and round:
-// 48 KiB (image, shared by four readers) + 12 KiB (three quarters) in, 12 + 12 KiB out -- a third of the ingest, at the
-// price of a second hand-off per step.
+// trials through the vector-memory path of every CU (1.5 MB per step), three barriers and 192 LDS-DMA pieces per round.
+// Here the 16 members form a 4 x 4 grid (jg, kg): member (jg, kg) keeps W_hh^T[units of group jg (128)][gate-gradient columns
+// of the units of group kg (3 x 128)] in registers (the same 196 KB) and needs only the K-SLICE kg of the gate gradients: 24 KiB
+// per round of 16 trials, ONE image, one barrier.  What it computes is a PARTIAL sum over its slice for the 128 units of group
+// jg; contraction wave w holds exactly the 32-unit quarter that member (jg, w) finishes, so it sends its accumulators straight
+// to that member (2 KiB, global memory / L2) and the gate waves of (jg, w) add the four quarters in a FIXED order.  A third of
+// the ingest of the 1-D kernel, at the price of a second hand-off per step.
 //
-//   iteration i = (ps - 1) * NR + r  (processing step ps >= 1, round r of 32 trials); slot s of the main loop:
-//     contraction waves : MFMAs of iteration s on image buffer s & 1, quarters out (own quarter: LDS ring slot s & 3)
-//     contraction waves : LDS-DMA of image s + 1 first, MFMAs of iteration s, quarters out, counted wait, flag of the quarters of
-//                         s - 1 (each wave for its own stores)
-//     gate waves        : flag of the gate gradients of s - 5, gate math of iteration s - 4 (exchange rows + outputs), requests
-//                         for the inputs of s - 2 (HBM: two slots ahead) and the quarters of s - 3 (L2: one slot ahead, behind
-//                         their flags), lookup of the flags of image s + 2.
-//   A gate gradient written in slot j + 4 is flagged in slot j + 5 and polled for image j + NR at the end of slot j + NR - 2:
-//   NR >= 8 rounds per cluster keep every first poll successful (cl_plan2).  Same protocol as above (sc1 loads, write-through
-//   or same-XCD write-back stores, counted vmcnt before the barrier, one lane's flag store after it); bounded spins.
+//   iteration i = (ps - 1) * NR + r  (processing step ps >= 1, round r of 16 trials); slot s of the main loop (one barrier):
+//     contraction waves : LDS-DMA of image s + 2 (ring of four), flag of the quarters of s - 1 (each wave for its own stores,
+//                         behind a counted wait), MFMAs of iteration s with a pinned three-deep fragment prefetch, quarters out
+//                         (own quarter: LDS ring)
+//     gate waves        : a round of 16 trials x 32 units is 128 lanes of work: the gate waves form two PAIRS that take the
+//                         iterations alternately, so every wave has two slots per iteration and each of its memory round
+//                         trips a whole slot to complete in:  slot i + 1: saved gates / dy / h_prev / running gradient of
+//                         iteration i requested (HBM);  slot i + 2: quarter flags, quarters requested (L2);  slot i + 3: gate
+//                         math, exchange rows, outputs;  slot i + 4: the wave flags its exchange rows (they are the oldest
+//                         operations still counted: the wait returns at once).  Wave 4 also looks the flags of image s + 3 up.
+//   NR >= 16 rounds per cluster and step: the whole chain (contraction i -> quarters -> gate math -> gate gradients -> image
+//   i + NR) spans 14 of 16 slots at most; lookups made a slot after publication hit unless the cluster is badly skewed.
+//   Protocol as above (sc1 loads, write-through or same-XCD write-back stores, counted vmcnt, flags stored by a lane of the
+//   storing wave / polled by the loading wave or in front of a barrier); bounded spins.
 //   One step per launch (XPS_GRU_CLUSTER=steps, or a grid the device cannot hold at once): the same kernel twice per step --
 //   contraction only, then gate math only -- with every quarter passed through global memory: same sums, same bits.
 //
-// Operand image: [trial 32][plane 2][384] bf16, trials 1536 B apart WITHOUT padding; instead 16-byte chunk q of trial n sits
-// at chunk q ^ (n & 15) of its 256-byte window -- applied by the LDS-DMA source addresses, undone by the fragment reads --
-// which makes the b128 reads of every 16-lane group hit 16 distinct bank quads (MI355X_MICROARCH.md, LDS lane groups).
+// Operand image: [trial 16][plane 2][384] bf16, trials 1536 B apart WITHOUT padding; 16-byte chunk q of trial n sits at chunk
+// q ^ n of its 256-byte window -- applied by the WRITERS of the gate gradients (the LDS-DMA is a linear copy: a piece whose
+// lanes fetch permuted chunks is split into per-lane requests and blocks its issuer ~650 instead of ~100 cycles), undone by
+// the fragment reads -- which makes the b128 reads of every 16-lane group hit 16 distinct bank quads.
 // ------------------------------------------------------------------------------------------------------
 struct ClBwd2 {
     const float* dy;
@@ -1039,9 +1051,10 @@ struct ClBwd2 {
     float* dghn;
     float* dh0;
     float* keep;                // [ndir][B][H]  z * dh of the step processed before
-    void* xbuf;                 // [2 parity][ndir][Bp/32][4 slices][32 trials][2 planes][384] bf16
-    float* pbuf;                // [2 parity][cluster][NR][16 dst][4 src][1024] partial quarters
-    unsigned* flags;            // [cluster][NR][160]: 16 words "gate gradients of step v - 1 published" + pad, then [16 dst][4 src] "quarter of step v published"
+    void* xbuf;                 // [2 parity][ndir][Bp/16][4 slices][16 trials][2 planes][384] bf16 (swizzled chunks)
+    float* pbuf;                // [2 parity][cluster][NR][16 dst][4 src][512] partial quarters
+    unsigned* flags;            // [cluster][NR][160]: [member 16][gate wave 4] "gate gradients of step v - 1 published", then
+                                // [dst 16][src 4] "quarter of step v published", pad
     unsigned* xcc;
     unsigned* status;
     unsigned* sticky;
@@ -1052,36 +1065,36 @@ struct ClBwd2 {
     int split_out;
 };
 
-constexpr int C2_IMG = 32 * 1536;           // one operand image
-#ifndef XPS_CL2_NT      // (non-temporal streams measured: 1106 vs 986 us per launch -- slower; not the default)
-#define CL2_STREAM_LOAD(ptr) (*reinterpret_cast<const f32x4*>(ptr))
-constexpr int CL2_AUX_STREAM = 0;
-#else
+#if defined(XPS_CL2_NT_LOADS)
 #define CL2_STREAM_LOAD(ptr) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr))
-constexpr int CL2_AUX_STREAM = 2;           // raw buffer builtins: bit 1 = nt
+#else
+#define CL2_STREAM_LOAD(ptr) (*reinterpret_cast<const f32x4*>(ptr))
 #endif
-constexpr int C2_LDS = 2 * C2_IMG + 4 * 4096 + 64;
+#if defined(XPS_CL2_NT_STORES)
+constexpr int CL2_AUX_STREAM = 2;           // raw buffer builtins: bit 1 = nt
+#elif defined(XPS_CL2_SC1_STORES)
+constexpr int CL2_AUX_STREAM = 16;          // write-through, line dropped from L2
+#else
+constexpr int CL2_AUX_STREAM = 0;
+#endif
+constexpr int C2_RT = 16;                   // trials per round
+constexpr int C2_IMG = C2_RT * 1536;        // one operand image
+constexpr int C2_NIMG = 4;                  // image ring
+constexpr int C2_LDS = C2_NIMG * C2_IMG + 4 * 2048 + 64;
 
-__device__ inline void cl_dma1(const unsigned char* gsrc, unsigned m0v) {
+// two 1-KiB LDS-DMA pieces (see cl_dma4)
+__device__ inline void cl_dma2(const unsigned char* gsrc, unsigned l0) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024 sc1\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(m0v));
-}
-
-// one piece, source = scalar base + 32-bit lane offset
-__device__ inline void cl_dma1s(const unsigned char* sbase, unsigned voff, unsigned m0v) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0v));
+                 : "=&s"(keep) : "v"(gsrc), "s"(l0));
 }
 
 __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ownq = smem + 2 * C2_IMG;           // ring of four own-quarter tiles (4 KiB each)
+    unsigned char* ownq = smem + C2_NIMG * C2_IMG;     // ring of four own-quarter tiles (2 KiB each)
     const unsigned lds0 = cl_lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1099,309 +1112,20 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     auto valid_c = [&](int i) { return i >= p.c_begin && i < p.c_end; };
     auto valid_g = [&](int i) { return i >= p.g_begin && i < p.g_end; };
     int s_lo = 0x7fffffff, s_hi = -0x7fffffff;
-    if (has_c) { s_lo = p.c_begin - 1; s_hi = p.c_end - 1; }
-    if (has_g) { s_lo = min(s_lo, p.g_begin + 1); s_hi = max(s_hi, p.g_end + 2); }
+    if (has_c) { s_lo = p.c_begin; s_hi = p.c_end - 1; }
+    if (has_g) { s_lo = min(s_lo, p.g_begin + 1); s_hi = max(s_hi, p.g_end + 3); }
 
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(p.pbuf, 0, p.pbuf_bytes, RSRC_FLAGS);
     // byte offset of the quarter tile (parity, round, destination member, source column) in pbuf
     auto p_off = [&](int ps_, int r_, int dst, int src) -> unsigned {
-        return (unsigned)((((((ps_ & 1) * nclusters + cm.cluster) * NR + r_) * 16 + dst) * 4 + src)) * 4096u;
+        return (unsigned)((((((ps_ & 1) * nclusters + cm.cluster) * NR + r_) * 16 + dst) * 4 + src)) * 2048u;
     };
     // chunk (one slice of one round) of the gate-gradient exchange buffer
     auto x_chunk = [&](int ps_src, int r_, int slice) -> unsigned {
-        return (unsigned)(((((ps_src & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r_) * 4 + slice)) * (unsigned)C2_IMG;
+        return (unsigned)(((((ps_src & 1) * p.ndir + dir) * (p.Bp / C2_RT) + (m_base / C2_RT) + r_) * 4 + slice)) * (unsigned)C2_IMG;
     };
-
-    if (wave < 4) {
-        // ---------------- contraction waves ----------------
-        // Besides the MFMAs they own every LDS-DMA of the kernel (12 pieces per wave and slot, issued FIRST: the MFMAs that
-        // follow cover the landing) and their own quarter hand-off: stores, a counted wait one slot later, then ONE lane's flag
-        // per wave (each storing wave signals for itself: MI355X_MICROARCH.md, "Valid forms", third table row).
-        if (p.do_ps0) { __syncthreads(); }
-        if (s_lo > s_hi) return;
-        // LDS-DMA of one image: a LINEAR copy of the 48-KiB chunk (the bank swizzle is applied by the WRITERS of the gate gradients:
-        // a piece whose lanes fetch permuted 16-byte chunks is split into per-lane requests and blocks its issuer ~650 cycles
-        // instead of ~80); wave w moves bytes [12 w, 12 w + 12) KiB in three groups of four 1-KiB pieces
-        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
-        auto dma_image = [&](int i) {
-            const int ps = i / NR + 1, r = i % NR;
-            const unsigned char* src = xb + x_chunk(ps - 1, r, kg) + wave * 12288 + lane * 16;
-            const unsigned dst = lds0 + (unsigned)((i & 1) * C2_IMG) + (unsigned)(wave * 12288);
-#pragma unroll
-            for (int g4 = 0; g4 < 3; ++g4) cl_dma4(src + g4 * 4096, dst + g4 * 4096, dst + g4 * 4096, dst + g4 * 4096, dst + g4 * 4096);
-        };
-        if (has_c && p.handoff) __syncthreads();           // (wave 4's poll for the first image)
-        if (has_c) {
-            dma_image(p.c_begin);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                                   // image of the first iteration has landed
-        const float* __restrict__ WT = p.w_hh_t[dir];
-        bf16x8 wh[2][12], wl[2][12];
-#pragma unroll
-        for (int ut = 0; ut < 2; ++ut) {
-            const int jr = jg * 128 + wave * 32 + ut * 16 + n;
-            const bool rlive = has_c && jr < H;                // (a gate-only launch contracts nothing: no weight traffic)
-            const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H;
-#pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const int ku = kg * 128 + (c & 3) * 32 + 8 * kq;
-                const float* src = wrow + (c >> 2) * H + ku;
-                const bool ok0 = rlive && ku + 3 < H, ok1 = rlive && ku + 7 < H;
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(ok0 ? src : WT);
-                f32x4 v1 = *reinterpret_cast<const f32x4*>(ok1 ? src + 4 : WT);
-                if (!ok0) v0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (!ok1) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 a, b;
-                    bf_split(v0[e], a, b); wh[ut][c][e] = a; wl[ut][c][e] = b;
-                    bf_split(v1[e], a, b); wh[ut][c][4 + e] = a; wl[ut][c][4 + e] = b;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the weight loads: the counted waits below assume an empty queue)
-        const bool own_lds = p.handoff && wave == kg;      // this wave's quarter is the member's own: through LDS
-        unsigned frag_lane[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) frag_lane[m] = (unsigned)(n * 1536 + ((((m ^ (n >> 2)) << 2) | (kq ^ (n & 3))) << 4));
-#ifdef XPS_CL_STAMP
-        unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sbA = 0, sbB = 0, s_bar = 0, s_work = 0, s_drain = 0, s_dma = 0, s_mma = 0;
-        CL_STAMP(sb2)
-#endif
-        for (int s = s_lo; s <= s_hi; ++s) {
-            // (1) the image of the next iteration (its flags were polled by wave 4 before the last barrier)
-            const bool dma_now = s + 1 != p.c_begin && valid_c(s + 1);
-            if (dma_now) dma_image(s + 1);
-            CL_FENCE();
-            // (2) the quarters stored at the end of the last slot are in memory by now (they had the barrier and the DMA issue):
-            //     this wave flags them for their reader before its MFMAs, not after
-            if (p.handoff && !own_lds && valid_c(s - 1)) {
-                if (dma_now) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    const int i = s - 1;
-                    __hip_atomic_store(myflags + (i % NR) * 160 + 64 + (jg * 4 + wave) * 4 + kg, (unsigned)(i / NR + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            CL_FENCE();
-            CL_STAMP(sbA)
-            int nst = 0;
-            if (valid_c(s)) {
-                const int ps = s / NR + 1, r = s % NR;
-                f32x4 acc[2][2];
-#pragma unroll
-                for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) acc[ut][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // 24 steps (trial tile, 32-wide k chunk); the fragments of step i + 2 are requested before the MFMAs of step i (a
-                // ring of three, pinned with scheduling barriers: left alone the scheduler issues every read right in front of
-                // its six MFMAs and exposes the LDS latency 24 times per slot: 7800 instead of ~2600 cycles).  Addresses: chunk
-                // (4 c + kq) ^ n = 16 (c >> 2) + (4 ((c & 3) ^ (n >> 2)) | (kq ^ (n & 3))): four lane offsets (by c & 3), the
-                // rest is an immediate.
-                unsigned fa[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) fa[m] = frag_lane[m] + (unsigned)((s & 1) * C2_IMG);
-                bf16x8 fh[3], fl[3];
-                auto frag = [&](int i, bf16x8& h8, bf16x8& l8) {
-                    const unsigned char* rp = smem + fa[(i % 12) & 3] + ((i / 12) * 16 * 1536 + ((i % 12) >> 2) * 256);
-                    h8 = *reinterpret_cast<const bf16x8*>(rp);
-                    l8 = *reinterpret_cast<const bf16x8*>(rp + 768);
-                };
-                frag(0, fh[0], fl[0]);
-                frag(1, fh[1], fl[1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 24; ++i) {
-                    const int tt = i / 12, c = i % 12;
-                    if (i + 2 < 24) frag(i + 2, fh[(i + 2) % 3], fl[(i + 2) % 3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const bf16x8 bh = fh[i % 3], bl = fl[i % 3];
-#pragma unroll
-                    for (int ut = 0; ut < 2; ++ut) {
-                        acc[ut][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ut][c], bh, acc[ut][tt], 0, 0, 0);
-                        acc[ut][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ut][c], bl, acc[ut][tt], 0, 0, 0);
-                        acc[ut][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ut][c], bh, acc[ut][tt], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                CL_STAMP(sbB)
-                CL_ACC(s_mma, sbA, sbB)
-                if (own_lds) {
-#pragma unroll
-                    for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt)
-                            *reinterpret_cast<f32x4*>(ownq + (s & 3) * 4096 + ((ut * 2 + tt) * 64 + lane) * 16) = acc[ut][tt];
-                } else {
-                    const unsigned base = p_off(ps, r, jg * 4 + wave, kg) + (unsigned)lane * 16u;
-#pragma unroll
-                    for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ut][tt]), pr, base + (unsigned)(ut * 2 + tt) * 1024u, 0, 0);
-                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ut][tt]), pr, base + (unsigned)(ut * 2 + tt) * 1024u, 0, AUX_SC1);
-                        }
-                    nst = 4;
-                }
-            }
-            CL_FENCE();
-            CL_STAMP(sb3)
-            // (3) everything but this slot's four stores is complete: the image of the next iteration has landed
-            if (nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CL_STAMP(sb0)
-            __syncthreads();
-            CL_STAMP(sb1)
-            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb0) CL_ACC(s_dma, sb2, sbA)
-#ifdef XPS_CL_STAMP
-            sb2 = sb1;
-#endif
-        }
-#ifdef XPS_CL_STAMP
-        if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 4] = s_dma; g_clstamp[wid * 8 + 5] = s_mma; }
-#endif
-        return;
-    }
-
-    // ---------------- gate waves ----------------
-    __builtin_amdgcn_s_setprio(3);
-    const int hw = wave - 4;
-    const int hut = hw >> 1, te = hw & 1;
-    const int uo = kg * 32 + hut * 16 + 4 * kq;           // this lane's four units inside group jg
-    const int ju = jg * 128 + uo;
-    const bool ulive = ju < H;
-    const int juc = ulive ? ju : 0;
-    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
-    __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgi, 0, (unsigned)((long long)p.ndir * T * B * 3 * H * 4), RSRC_FLAGS);
-    __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(p.dghn, 0, (unsigned)((long long)p.ndir * T * B * H * 4), RSRC_FLAGS);
-    __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
-    const bool has_dy = p.dy != nullptr;
-
-    struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
-    auto epi_load = [&](int ps, int r, EpiIn& in) -> int {
-        const int s_ = T - 1 - ps;
-        const int t = (dir == 0) ? s_ : T - 1 - s_;
-        const int slot_prev = (dir == 0) ? t : t + 2;
-        const int b = m_base + 32 * r + 16 * te + n;
-        const int bc = b < B ? b : B - 1;
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        int nload = 0;
-        in.keep = (u32x4){0u, 0u, 0u, 0u};
-#ifdef XPS_CL2_ABL_NOLOAD
-        in.dy = z4 + 0.01f; in.rg = z4 + 0.5f; in.zg = z4 + 0.4f; in.ng = z4 + 0.1f; in.q = z4 + 0.2f; in.hp = z4 + 0.3f;
-        (void)slot_prev; (void)bc;
-        return 0;
-#endif
-        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1); ++nload; }
-        else if (p.dhn) { in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc)); ++nload; }
-        if (ps < T) {
-            in.dy = z4;
-            // read-once streams: non-temporal, so that they do not push the exchange lines (re-read a few slots after they were
-            // written) out of the XCD's 4-MiB L2 -- an LDS-DMA piece that misses L2 blocks its issuer ~650 instead of ~100 cycles
-            if (has_dy) { in.dy = CL2_STREAM_LOAD(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc); ++nload; }
-            const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
-            in.rg = CL2_STREAM_LOAD(sv);
-            in.zg = CL2_STREAM_LOAD(sv + H);
-            in.ng = CL2_STREAM_LOAD(sv + 2 * H);
-            in.q = CL2_STREAM_LOAD(sv + 3 * H);
-            in.hp = CL2_STREAM_LOAD(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
-            nload += 5;
-        } else {
-            in.dy = z4; in.rg = z4; in.zg = z4; in.ng = z4; in.q = z4; in.hp = z4;
-        }
-        return nload;
-    };
-    // gate gradients of processing step ps, round r for this lane's trial and four units; acc = dgh_{ps-1} W_hh (own units).
-    // Stores: the exchange rows first, then the outputs (always issued: dead lanes are dropped by the range check).
-    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc, auto&& before_stores) {
-        const int s_ = T - 1 - ps;
-        const int t = (dir == 0) ? s_ : T - 1 - s_;
-        const int b = m_base + 32 * r + 16 * te + n;
-        bool live = b < B && ulive;
-        f32x4 carry = __builtin_bit_cast(f32x4, in.keep);
-        if (ps > 0) carry += acc;
-        if (ps == T) {
-            before_stores();
-            CL_FENCE();
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, carry), hr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
-            return;
-        }
-        f32x4 dar, daz, dan, danr, keep;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dh = in.dy[i] + carry[i];
-            const float r_ = in.rg[i], z_ = in.zg[i], n_ = in.ng[i];
-            const float dn = dh * (1.f - z_);
-            const float dz = dh * (in.hp[i] - n_);
-            const float da = dn * (1.f - n_ * n_);
-            daz[i] = live ? dz * z_ * (1.f - z_) : 0.f;
-            dar[i] = live ? da * in.q[i] * r_ * (1.f - r_) : 0.f;
-            dan[i] = da;
-            danr[i] = live ? da * r_ : 0.f;
-            keep[i] = dh * z_;
-        }
-        // (the next iteration's quarter requests go out between the arithmetic and this iteration's eleven stores)
-        CL_FENCE();
-        before_stores();
-        CL_FENCE();
-        if (ps + 1 < p.ps_total) {                      // someone will contract these gradients: slice jg of round r
-            // row of trial (16 te + n), plane-row byte L = 2 (128 g + uo) -> 16-byte chunk (L >> 4) ^ n of its 256-byte window
-            // (the operand image's bank swizzle, see the kernel header; n = trial & 15), byte L & 15 inside the chunk
-            const unsigned base = x_chunk(ps, r, jg) + (unsigned)(16 * te + n) * 1536u;
-            const unsigned Lq = (unsigned)uo >> 3, Lw = ((unsigned)uo & 4u) << 1;
-            const f32x4* gsrc[3] = {&dar, &daz, &danr};
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                bf16x4 sh, sl;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split((*gsrc[g])[i], a, c); sh[i] = a; sl[i] = c; }
-                const unsigned o = base + ((((unsigned)(16 * g) + Lq) ^ (unsigned)n) << 4) + Lw;
-                if (fast) {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, AUX_SC1);
-                }
-            }
-        }
-        CL_FENCE();
-#ifdef XPS_CL2_ABL_NOSTORE
-        const unsigned go = (b == -12345) ? 0u : CL_OOB;      // every output store dropped by the range check
-        live = false;
-#else
-        const unsigned go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
-#endif
-        if (p.split_out) { dar = split4_pack(dar); daz = split4_pack(daz); dan = split4_pack(dan); danr = split4_pack(danr); }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dar), gr, go, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
-    };
-
-    if (p.do_ps0) {
-        // first processing step: no contraction, the running gradient starts from dhn (or zero)
-        for (int r = 0; r < NR; ++r) {
-            EpiIn in;
-            epi_load(0, r, in);
-            epilogue(0, r, in, (f32x4){0.f, 0.f, 0.f, 0.f}, [] {});
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int r = 0; p.handoff && r < NR; r += 64)          // (every gate wave for its own stores)
-            if (r + lane < NR) __hip_atomic_store(myflags + (r + lane) * 160 + cm.member * 4 + hw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-    }
-    if (s_lo > s_hi) return;
-
-    // polls (wave 4).  Flags of a round r: words [0, 16) "gate gradients of step v - 1 published" per member (one lane's store
-    // behind the workgroup's counted waits and barrier); words [32 + 4 dst, 32 + 4 dst + 4) "quarter of step v for member dst
-    // from column src published" (the storing contraction wave's own flag).  The image of iteration i needs the gate gradients
-    // of step ps - 1 from the members (kg, 0..3); the gate math of iteration i the quarters of step ps from the columns c != kg.
-    // Both are looked up at the START of a slot (the loads are in flight during the gate math) and, on a miss, polled at its end.
+    // flags of round r: words [4 m, 4 m + 4) gate gradients of member m (one word per gate wave), words [64 + 4 dst, + 4) quarters
     auto flag_image = [&](int i) -> const unsigned* { return myflags + (i % NR) * 160 + kg * 16; };
     auto flag_quarters = [&](int i) -> const unsigned* { return myflags + (i % NR) * 160 + 64 + cm.member * 4; };
     // (skip_own: the four quarter flags of this member, its own column excluded; else: the 16 gate-gradient flags -- four gate
@@ -1429,89 +1153,331 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
         }
     };
 
-    // the image of the first iteration: its flags (persistent form), then the contraction waves' LDS-DMA; barriers mirror theirs
+    if (wave < 4) {
+        // ---------------- contraction waves ----------------
+        if (p.do_ps0) { __syncthreads(); }
+        if (s_lo > s_hi) return;
+        // LDS-DMA of one image: a linear copy of the 24-KiB chunk; wave w moves bytes [6 w, 6 w + 6) KiB
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+        auto dma_image = [&](int i) {
+            const int ps = i / NR + 1, r = i % NR;
+            const unsigned char* src = xb + x_chunk(ps - 1, r, kg) + wave * 6144 + lane * 16;
+            const unsigned dst = lds0 + (unsigned)((i & (C2_NIMG - 1)) * C2_IMG) + (unsigned)(wave * 6144);
+            cl_dma4(src, dst, dst, dst, dst);
+            cl_dma2(src + 4096, dst + 4096);
+        };
+        if (has_c && p.handoff) __syncthreads();           // (wave 4's polls for the first three images)
+        if (has_c) {
+            dma_image(p.c_begin);
+            if (valid_c(p.c_begin + 1)) dma_image(p.c_begin + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                   // the first images have landed
+        const float* __restrict__ WT = p.w_hh_t[dir];
+        bf16x8 wh[2][12], wl[2][12];
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut) {
+            const int jr = jg * 128 + wave * 32 + ut * 16 + n;
+            const bool rlive = has_c && jr < H;                // (a gate-only launch contracts nothing: no weight traffic)
+            const float* wrow = WT + (long long)(rlive ? jr : 0) * 3 * H;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const int ku = kg * 128 + (c & 3) * 32 + 8 * kq;
+                const float* src = wrow + (c >> 2) * H + ku;
+                const bool ok0 = rlive && ku + 3 < H, ok1 = rlive && ku + 7 < H;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(ok0 ? src : WT);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(ok1 ? src + 4 : WT);
+                if (!ok0) v0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!ok1) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a_, b_;
+                    bf_split(v0[e], a_, b_); wh[ut][c][e] = a_; wl[ut][c][e] = b_;
+                    bf_split(v1[e], a_, b_); wh[ut][c][4 + e] = a_; wl[ut][c][4 + e] = b_;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the weight loads: the counted waits below assume an empty queue)
+        const bool own_lds = p.handoff && wave == kg;      // this wave's quarter is the member's own: through LDS
+        // fragment addresses: chunk (4 c + kq) ^ n = 16 (c >> 2) + (4 ((c & 3) ^ (n >> 2)) | (kq ^ (n & 3))): four lane offsets (by
+        // c & 3), the rest is an immediate
+        unsigned frag_lane[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) frag_lane[m] = (unsigned)(n * 1536 + ((((m ^ (n >> 2)) << 2) | (kq ^ (n & 3))) << 4));
+#ifdef XPS_CL_STAMP
+        unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sbA = 0, sbB = 0, s_bar = 0, s_work = 0, s_drain = 0, s_dma = 0, s_mma = 0;
+        CL_STAMP(sb2)
+#endif
+        for (int s = s_lo; s <= s_hi; ++s) {
+            // (1) the image of iteration s + 2 (its flags were looked up by wave 4 before the last barrier)
+            const bool dma_now = valid_c(s + 2);
+            if (dma_now) dma_image(s + 2);
+            CL_FENCE();
+            // (2) the quarters stored at the end of the last slot are in memory by now (they had the barrier and the DMA issue):
+            //     this wave flags them for their reader
+            if (p.handoff && !own_lds && valid_c(s - 1)) {
+                if (dma_now) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const int i = s - 1;
+                    __hip_atomic_store(myflags + (i % NR) * 160 + 64 + (jg * 4 + wave) * 4 + kg, (unsigned)(i / NR + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            CL_FENCE();
+            CL_STAMP(sbA)
+            if (valid_c(s)) {
+                const int ps = s / NR + 1, r = s % NR;
+                f32x4 acc[2];
+                acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[1] = acc[0];
+                // 12 steps (32-wide k chunks); the fragments of step i + 2 are requested before the MFMAs of step i (a ring of
+                // three, pinned with scheduling barriers: left alone the scheduler issues every read right in front of its six
+                // MFMAs and exposes the LDS latency every time)
+                unsigned fa[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) fa[m] = frag_lane[m] + (unsigned)((s & (C2_NIMG - 1)) * C2_IMG);
+                bf16x8 fh[3], fl[3];
+                auto frag = [&](int i, bf16x8& h8, bf16x8& l8) {
+                    const unsigned char* rp = smem + fa[i & 3] + (i >> 2) * 256;
+                    h8 = *reinterpret_cast<const bf16x8*>(rp);
+                    l8 = *reinterpret_cast<const bf16x8*>(rp + 768);
+                };
+                frag(0, fh[0], fl[0]);
+                frag(1, fh[1], fl[1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    if (i + 2 < 12) frag(i + 2, fh[(i + 2) % 3], fl[(i + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 bh = fh[i % 3], bl = fl[i % 3];
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut) {
+                        acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ut][i], bh, acc[ut], 0, 0, 0);
+                        acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ut][i], bl, acc[ut], 0, 0, 0);
+                        acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ut][i], bh, acc[ut], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                CL_STAMP(sbB)
+                CL_ACC(s_mma, sbA, sbB)
+                if (own_lds) {
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut)
+                        *reinterpret_cast<f32x4*>(ownq + (s & 3) * 2048 + (ut * 64 + lane) * 16) = acc[ut];
+                } else {
+                    const unsigned base = p_off(ps, r, jg * 4 + wave, kg) + (unsigned)lane * 16u;
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut) {
+                        if (fast) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ut]), pr, base + (unsigned)ut * 1024u, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ut]), pr, base + (unsigned)ut * 1024u, 0, AUX_SC1);
+                    }
+                }
+            }
+            CL_FENCE();
+            CL_STAMP(sb3)
+            // (3) the image of iteration s + 1 (requested a slot ago) has landed: everything older than this slot's operations
+            //     (6 pieces, 1 flag, 2 stores -- those that were issued) is complete
+            cl_wait_vmcnt((dma_now ? 6 : 0) + ((p.handoff && !own_lds && valid_c(s - 1)) ? 1 : 0) + ((valid_c(s) && !own_lds) ? 2 : 0));
+            CL_STAMP(sb0)
+            __syncthreads();
+            CL_STAMP(sb1)
+            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb0) CL_ACC(s_dma, sb2, sbA)
+#ifdef XPS_CL_STAMP
+            sb2 = sb1;
+#endif
+        }
+#ifdef XPS_CL_STAMP
+        if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 4] = s_dma; g_clstamp[wid * 8 + 5] = s_mma; }
+#endif
+        return;
+    }
+
+    // ---------------- gate waves ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int hw = wave - 4;
+    const int pair = hw >> 1, hut = hw & 1;               // pair: takes the iterations i with i % 2 == pair; unit tile
+    const int uo = kg * 32 + hut * 16 + 4 * kq;           // this lane's four units inside group jg
+    const int ju = jg * 128 + uo;
+    const bool ulive = ju < H;
+    const int juc = ulive ? ju : 0;
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgi, 0, (unsigned)((long long)p.ndir * T * B * 3 * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(p.dghn, 0, (unsigned)((long long)p.ndir * T * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
+    const bool has_dy = p.dy != nullptr;
+
+    struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
+    auto epi_load = [&](int ps, int r, EpiIn& in) -> int {
+        const int s_ = T - 1 - ps;
+        const int t = (dir == 0) ? s_ : T - 1 - s_;
+        const int slot_prev = (dir == 0) ? t : t + 2;
+        const int b = m_base + C2_RT * r + n;
+        const int bc = b < B ? b : B - 1;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        int nload = 0;
+        in.keep = (u32x4){0u, 0u, 0u, 0u};
+        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1); ++nload; }
+        else if (p.dhn) { in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc)); ++nload; }
+        if (ps < T) {
+            in.dy = z4;
+            if (has_dy) { in.dy = CL2_STREAM_LOAD(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc); ++nload; }
+            const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+            in.rg = CL2_STREAM_LOAD(sv);
+            in.zg = CL2_STREAM_LOAD(sv + H);
+            in.ng = CL2_STREAM_LOAD(sv + 2 * H);
+            in.q = CL2_STREAM_LOAD(sv + 3 * H);
+            in.hp = CL2_STREAM_LOAD(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
+            nload += 5;
+        } else {
+            in.dy = z4; in.rg = z4; in.zg = z4; in.ng = z4; in.q = z4; in.hp = z4;
+        }
+        return nload;
+    };
+    // gate gradients of processing step ps, round r for this lane's trial and four units; acc = dgh_{ps-1} W_hh (own units).
+    // Stores: the exchange rows first, then the outputs (always issued: dead lanes are dropped by the range check).
+    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) {
+        const int s_ = T - 1 - ps;
+        const int t = (dir == 0) ? s_ : T - 1 - s_;
+        const int b = m_base + C2_RT * r + n;
+        const bool live = b < B && ulive;
+        f32x4 carry = __builtin_bit_cast(f32x4, in.keep);
+        if (ps > 0) carry += acc;
+        if (ps == T) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, carry), hr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+            return;
+        }
+        f32x4 dar, daz, dan, danr, keep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dh = in.dy[i] + carry[i];
+            const float r_ = in.rg[i], z_ = in.zg[i], n_ = in.ng[i];
+            const float dn = dh * (1.f - z_);
+            const float dz = dh * (in.hp[i] - n_);
+            const float da = dn * (1.f - n_ * n_);
+            daz[i] = live ? dz * z_ * (1.f - z_) : 0.f;
+            dar[i] = live ? da * in.q[i] * r_ * (1.f - r_) : 0.f;
+            dan[i] = da;
+            danr[i] = live ? da * r_ : 0.f;
+            keep[i] = dh * z_;
+        }
+        if (ps + 1 < p.ps_total) {                      // someone will contract these gradients: slice jg of round r
+            // row of trial n, plane-row byte L = 2 (128 g + uo) -> 16-byte chunk (L >> 4) ^ n of its 256-byte window (the operand
+            // image's bank swizzle, see the kernel header), byte L & 15 inside the chunk
+            const unsigned base = x_chunk(ps, r, jg) + (unsigned)n * 1536u;
+            const unsigned Lq = (unsigned)uo >> 3, Lw = ((unsigned)uo & 4u) << 1;
+            const f32x4* gsrc[3] = {&dar, &daz, &danr};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                bf16x4 sh, sl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __bf16 a_, c_; bf_split((*gsrc[g])[i], a_, c_); sh[i] = a_; sl[i] = c_; }
+                const unsigned o = base + ((((unsigned)(16 * g) + Lq) ^ (unsigned)n) << 4) + Lw;
+                if (fast) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, AUX_SC1);
+                }
+            }
+        }
+        CL_FENCE();
+        const unsigned go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
+        if (p.split_out) { dar = split4_pack(dar); daz = split4_pack(daz); dan = split4_pack(dan); danr = split4_pack(danr); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dar), gr, go, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+    };
+
+    if (p.do_ps0) {
+        // first processing step: no contraction, the running gradient starts from dhn (or zero); pair P takes the rounds r % 2 == P
+        for (int r = pair; r < NR; r += 2) {
+            EpiIn in;
+            epi_load(0, r, in);
+            epilogue(0, r, in, (f32x4){0.f, 0.f, 0.f, 0.f});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int r = pair + 2 * lane; p.handoff && r < NR; r += 128)      // (every gate wave for its own stores; two words per member and round)
+            for (int k = 0; k < 2; ++k)
+                __hip_atomic_store(myflags + r * 160 + cm.member * 4 + 2 * k + hut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    if (s_lo > s_hi) return;
+
+    // the first three images: their flags (persistent form), then the contraction waves' LDS-DMA of two; barriers mirror theirs
     if (has_c && p.handoff) {
-        if (wave == 4) wait_flags(flag_image(p.c_begin), false, (unsigned)(p.c_begin / NR + 1), 0u, 1);
+        if (wave == 4)
+            for (int i = p.c_begin; i < p.c_begin + 3 && valid_c(i); ++i)
+                wait_flags(flag_image(i), false, (unsigned)(i / NR + 1), 0u, 1);
         __syncthreads();
     }
     __syncthreads();
 
-    // Gate-wave slot s (see the header): the inputs of a gate math travel two slots (saved gates / dy / h_prev / running gradient:
-    // HBM) and one slot (quarters: L2) ahead of it, in two register sets that alternate by slot parity (the loop body is
-    // instantiated per parity: no copies, no dynamic register index).  Every gate wave looks its own quarter flags up at the
-    // start of a slot -- published a whole slot earlier, so the lookup hits unless the cluster is badly skewed -- and requests the
-    // quarters once it has matched (the polling wave loads behind its own matched poll: no barrier needed).
-    EpiIn ein[2];
-    f32x4 pqs[2][4];                                    // quarters: requested into set `par` in one slot, summed from it in the next
+    // A round of 16 trials is the work of ONE pair; the other pair takes the next.  Wave of pair P, slot s:
+    //   s % 2 != P ("math slot", i = s - 3 has i % 2 == P): gate math of iteration s - 3, then the HBM requests of iteration s - 1
+    //   s % 2 == P ("request slot"): flag of its exchange rows of iteration s - 4, quarter flags and quarters of iteration s - 2
+    // (iteration i: requests in slot i + 1 and i + 2, math in slot i + 3, flag in slot i + 4: two slots per memory round trip)
+    EpiIn ein;
+    f32x4 pq[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { pqs[0][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; pqs[1][c] = pqs[0][c]; }
+    for (int c = 0; c < 4; ++c) pq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int after_rows = 0;                                    // operations issued behind the exchange rows of the last math slot
 #ifdef XPS_CL_STAMP
-    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, sbA = 0, sbB = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0, s_math = 0, s_q = 0;
+    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0, s_math = 0, s_q = 0;
     CL_STAMP(sb2)
 #endif
-    int prev_younger = 0;
-    auto slot_body = [&](int s, auto PAR) {
-        constexpr int par = decltype(PAR)::value;
-        // (1) flag: this wave's exchange rows of iteration s - 4 (stored in slot s - 1: the oldest operations still counted; a
-        //     whole barrier later they are complete and the wait returns at once -- nothing waits for store completion BEFORE a
-        //     barrier); lookups: image of iteration s + 2 (wave 4), quarters of iteration s - 2 (every gate wave; flagged by
-        //     their contraction waves early in slot s - 1)
-        unsigned la_img = 0xffffffffu, la_q = 0xffffffffu;
-        if (p.handoff) {
-            if (valid_g(s - 4)) {
+    for (int s = s_lo; s <= s_hi; ++s) {
+        unsigned la_img = 0xffffffffu;
+        if (p.handoff && wave == 4 && valid_c(s + 3)) la_img = peek(flag_image(s + 3), false);
+        CL_FENCE();
+        if (((s - pair) & 1) != 0) {
+            // ---- math slot ----
+            int younger = 0;
+            if (valid_g(s - 3)) {
+                const int i = s - 3, ps = i / NR + 1;
+                const f32x4 a = ((pq[0] + pq[1]) + pq[2]) + pq[3];
+                epilogue(ps, i % NR, ein, a);
+                younger += ps == T ? 1 : 5;
+            }
+            CL_FENCE();
+            if (valid_g(s - 1)) younger += epi_load((s - 1) / NR + 1, (s - 1) % NR, ein);
+            after_rows = younger;
+            CL_STAMP(sb3)
+            CL_ACC(s_math, sb2, sb3)
+        } else {
+            // ---- request slot ----
+            if (p.handoff && valid_g(s - 4)) {
                 const int i = s - 4, ps = i / NR + 1;
                 if (ps + 1 < p.ps_total) {
-                    cl_wait_vmcnt(prev_younger);
-                    if (lane == 0) __hip_atomic_store(myflags + (i % NR) * 160 + cm.member * 4 + hw, (unsigned)(ps + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cl_wait_vmcnt(after_rows);               // the exchange rows of slot s - 1: the oldest operations still counted
+                    if (lane == 0) {
+                        unsigned* f = myflags + (i % NR) * 160 + cm.member * 4 + hut;
+                        __hip_atomic_store(f, (unsigned)(ps + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(f + 2, (unsigned)(ps + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
-            if (wave == 4 && valid_c(s + 2)) la_img = peek(flag_image(s + 2), false);
-            if (valid_g(s - 2)) la_q = peek(flag_quarters(s - 2), true);
-        }
-        CL_FENCE();
-        // (3) quarter requests of iteration s - 2 (own one: LDS; when every step is a launch: all four from global memory), issued
-        //     from inside the gate math below, between its arithmetic and its stores
-        int nq = 0;
-        auto request_quarters = [&]() {
-            if (!valid_g(s - 2)) return;
-            const int i = s - 2, ps = i / NR + 1, r = i % NR;
-            if (p.handoff) wait_flags(flag_quarters(i), true, (unsigned)ps, la_q, 6);
-            const unsigned tile = (unsigned)(((hut * 2 + te) * 64 + lane) * 16);
+            CL_FENCE();
+            if (valid_g(s - 2)) {
+                const int i = s - 2, ps = i / NR + 1, r = i % NR;
+                if (p.handoff) wait_flags(flag_quarters(i), true, (unsigned)ps, peek(flag_quarters(i), true), 6);
+                const unsigned tile = (unsigned)((hut * 64 + lane) * 16);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (p.handoff && c == kg) {
-                    pqs[par][c] = *reinterpret_cast<const f32x4*>(ownq + (i & 3) * 4096 + tile);
-                } else {
-                    pqs[par][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, p_off(ps, r, cm.member, c) + tile, 0, AUX_SC1));
-                    ++nq;
+                for (int c = 0; c < 4; ++c) {
+                    if (p.handoff && c == kg) pq[c] = *reinterpret_cast<const f32x4*>(ownq + (i & 3) * 2048 + tile);
+                    else pq[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, p_off(ps, r, cm.member, c) + tile, 0, AUX_SC1));
                 }
             }
-        };
-        // (2) gate math of iteration s - 3 (quarters requested in slot s - 1, the rest in slot s - 2)
-        int younger = 0;
-        if (valid_g(s - 3)) {
-            const int i = s - 3, ps = i / NR + 1;
-            const f32x4 a = ((pqs[1 - par][0] + pqs[1 - par][1]) + pqs[1 - par][2]) + pqs[1 - par][3];
-            epilogue(ps, i % NR, ein[par], a, request_quarters);
-            younger += ps == T ? 1 : 5;                      // the stores behind the exchange rows
-        } else {
-            request_quarters();
+            CL_STAMP(sb3)
+            CL_ACC(s_q, sb2, sb3)
         }
         CL_FENCE();
-        CL_STAMP(sbA)
-        CL_ACC(s_math, sb2, sbA)
-        // (4) the inputs of the gate math of iteration s - 1 (two slots ahead; into the set this slot's gate math has released)
-        if (valid_g(s - 1)) younger += epi_load((s - 1) / NR + 1, (s - 1) % NR, ein[par]);
-        CL_FENCE();
-        CL_STAMP(sbB)
-        CL_ACC(s_q, sbA, sbB)
-        CL_STAMP(sb3)
-        // nothing to drain here: the exchange rows are flagged in the next slot (see (1)); `younger` operations follow them.  NB the
-        // quarter requests were issued BEFORE the exchange rows: they are older and complete with them
-        prev_younger = younger;
         CL_STAMP(sb4)
-        // (5) the image of iteration s + 2 is DMA'd in the next slot: its flags must have matched before the barrier
-        if (p.handoff && wave == 4 && valid_c(s + 2)) wait_flags(flag_image(s + 2), false, (unsigned)((s + 2) / NR + 1), la_img, 1);
+        // the image of iteration s + 3 is DMA'd in the next slot: its flags must have matched before the barrier
+        if (p.handoff && wave == 4 && valid_c(s + 3)) wait_flags(flag_image(s + 3), false, (unsigned)((s + 3) / NR + 1), la_img, 1);
         CL_STAMP(sb0)
         __syncthreads();
         CL_STAMP(sb1)
@@ -1519,10 +1485,6 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
 #ifdef XPS_CL_STAMP
         sb2 = sb1;
 #endif
-    };
-    for (int s = s_lo; s <= s_hi; s += 2) {
-        slot_body(s, std::integral_constant<int, 0>{});
-        if (s + 1 <= s_hi) slot_body(s + 1, std::integral_constant<int, 1>{});
     }
 #ifdef XPS_CL_STAMP
     if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; g_clstamp[wid * 8 + 4] = s_math; g_clstamp[wid * 8 + 5] = s_q; }
@@ -1612,8 +1574,18 @@ ClPlan cl_plan(int B, int H, int ndir) {
     return pl;
 }
 
-// 2-D cluster BPTT (gru_cluster2_bwd_kernel): bf16x3 mode, 384 < H <= 512, clusters of 16 = 4 x 4, >= 8 rounds of 32 trials
-// per cluster (the two hand-offs of a step span 7 slots of the round pipeline).  XPS_GRU_CL2=0: the 1-D kernel everywhere.
+// 2-D cluster BPTT (gru_cluster2_bwd_kernel): bf16x3 mode, 384 < H <= 512, clusters of 16 = 4 x 4, >= 16 rounds of 16 trials
+// per cluster (the two hand-offs of a step span 14 slots of the round pipeline).
+// Opt-in (xps_set_gru_bptt_grid(1) / XPS_GRU_CL2=1).  Measured on the configs[3] shard (one bidirectional H = 512 layer, 2048 trials,
+// 20 steps): 1.00-1.03 ms per launch against 0.98-1.02 ms of the 1-D kernel, step 7.45 vs 7.30 ms, HBM-side traffic 4.0 GB vs
+// 3.4 GB (PMC): both kernels move their bytes at ~3.5-4 TB/s and NONE of the exchanged bytes is served from the XCD's L2 (they
+// are consumed a step after they were written: 25 MB of stream traffic per XCD later), so the second hand-off of the 2-D grid
+// (the partial-sum quarters: +1 GB written and re-fetched) costs what its three-fold smaller LDS-DMA ingest saves.  DESIGN.md 4.5.
+int g_cl2 = -1;
+bool cl2_enabled() {
+    if (g_cl2 < 0) { const char* e = getenv("XPS_GRU_CL2"); g_cl2 = (e && e[0] == '1') ? 1 : 0; }
+    return g_cl2 != 0;
+}
 struct ClPlan2 {
     bool ok;
     int nblk, Mc, NR, Bp, grid;
@@ -1622,8 +1594,7 @@ struct ClPlan2 {
 ClPlan2 cl_plan2(int B, int H, int ndir) {
     ClPlan2 pl;
     memset(&pl, 0, sizeof(pl));
-    static const bool enabled = [] { const char* e = getenv("XPS_GRU_CL2"); return !(e && e[0] == '0'); }();
-    if (!enabled || cl_mode() == 0 || H <= 384 || H > 512 || (H % 4) != 0 || B < 128) return pl;
+    if (!cl2_enabled() || cl_mode() == 0 || H <= 384 || H > 512 || (H % 4) != 0 || B < 128) return pl;
     const int max_blk = cl_num_cus() / (16 * ndir);
     if (max_blk < 1) return pl;
     int nblk = B / 256;
@@ -1633,14 +1604,14 @@ ClPlan2 cl_plan2(int B, int H, int ndir) {
     const int per = (B + nblk - 1) / nblk;
     pl.Mc = ((per + 31) / 32) * 32;
     if (pl.Mc < 256) pl.Mc = 256;
-    pl.NR = pl.Mc / 32;
+    pl.NR = pl.Mc / C2_RT;
     pl.Bp = pl.nblk * pl.Mc;
     pl.grid = ndir * pl.nblk * 16;
     // header: flags [cluster][NR][160], XCC table [cluster][16], padding, status block (last 256 B); zeroed before every launch
     pl.flags_bytes = (((size_t)ndir * pl.nblk * (pl.NR * 160 + 16) * 4 + 256 + 255) / 256) * 256;
     pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
-    pl.xbuf = (size_t)2 * ndir * (pl.Bp / 32) * 4 * C2_IMG;
-    pl.pbuf = (size_t)2 * ndir * pl.nblk * pl.NR * 64 * 4096;
+    pl.xbuf = (size_t)2 * ndir * (pl.Bp / C2_RT) * 4 * C2_IMG;
+    pl.pbuf = (size_t)2 * ndir * pl.nblk * pl.NR * 64 * 2048;
     pl.ok = pl.xbuf < ((size_t)1 << 31) && pl.pbuf < ((size_t)1 << 32);
     return pl;
 }
@@ -1881,3 +1852,9 @@ extern "C" int xps_set_gru_cluster_mode(int mode) {
     return XPS_OK;
 }
 extern "C" int xps_get_gru_cluster_mode(void) { return cl_mode(); }
+extern "C" int xps_set_gru_bptt_grid(int two_dimensional) {
+    if (two_dimensional != 0 && two_dimensional != 1) { xps_set_error("xps_set_gru_bptt_grid: 0 (1-D cluster kernel) or 1 (4 x 4 grid)"); return XPS_E_INVALID; }
+    g_cl2 = two_dimensional;
+    return XPS_OK;
+}
+extern "C" int xps_get_gru_bptt_grid(void) { return cl2_enabled() ? 1 : 0; }

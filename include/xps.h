@@ -156,6 +156,12 @@ long long xps_gru_seq_status_offset(int T, int B, int H, int ndir);
  * keeping every launch's workspace alive.  The persistent form is only launched when the occupancy query says the device
  * holds the whole grid at once; otherwise (and always with mode 1) the same kernels run one step per launch.               */
 int xps_gru_set_status_word(unsigned* device_word);
+/* BPTT kernel of the cluster path in bf16x3 mode, 384 < H <= 512: 0 (default) = every member of a 16-workgroup cluster contracts
+ * all 3H gate-gradient columns of its trials; 1 (XPS_GRU_CL2=1) = the members form a 4 x 4 grid, contract one K slice each and
+ * exchange partial sums (a third of the LDS-DMA ingest, a second hand-off per step; same results up to summation order;
+ * measured on a par: DESIGN.md 4.5).  Process-wide, read at call time; the workspace query covers both.                       */
+int xps_set_gru_bptt_grid(int two_dimensional);
+int xps_get_gru_bptt_grid(void);
 int xps_set_gru_cluster_mode(int mode);
 int xps_get_gru_cluster_mode(void);
 int xps_gru_seq_fwd_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,

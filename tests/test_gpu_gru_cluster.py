@@ -32,6 +32,16 @@ def cluster_mode():
     lib().xps_set_gru_cluster_mode(old)
 
 
+@pytest.fixture(params=['grid1d', 'grid2d'])
+def bptt_grid(request):
+    """Both BPTT kernels of the cluster path (include/xps.h xps_set_gru_bptt_grid): the 1-D cluster kernel (default) and the
+    4 x 4 grid with partial-sum hand-off (taken for 384 < H <= 512 in bf16x3 mode; other shapes run the 1-D kernel either way)."""
+    old = lib().xps_get_gru_bptt_grid()
+    assert lib().xps_set_gru_bptt_grid(1 if request.param == 'grid2d' else 0) == 0
+    yield request.param
+    lib().xps_set_gru_bptt_grid(old)
+
+
 def _weights(gru, ndir):
     out = []
     for d in range(ndir):
@@ -54,7 +64,7 @@ def test_cluster_path_is_selected_for_the_north_star_shapes():
 @pytest.mark.parametrize('mode', ['persistent', 'steps'])
 @pytest.mark.parametrize('T,B,In,H,ndir', [(6, 256, 24, 512, 2), (5, 200, 16, 500, 2), (4, 130, 12, 320, 1), (3, 300, 10, 260, 2),
                                            (7, 160, 20, 448, 1), (2, 1030, 8, 388, 2)])
-def test_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir, mode, gemm_precision, cluster_mode):
+def test_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir, mode, gemm_precision, cluster_mode, bptt_grid):
     """Whole layer (input projection + recurrence + BPTT + weight gradients) against torch.nn.GRU on the CPU; same
     tolerances as the H <= 128 kernels (tests/test_gpu_nn_kernels.py)."""
     cluster_mode(mode)
@@ -88,7 +98,7 @@ def test_layer_forward_backward_vs_torch_cpu(T, B, In, H, ndir, mode, gemm_preci
 
 
 @pytest.mark.parametrize('H,ndir', [(512, 2), (288, 1)])
-def test_recurrence_with_initial_state_and_its_gradient(H, ndir, gemm_precision):
+def test_recurrence_with_initial_state_and_its_gradient(H, ndir, gemm_precision, bptt_grid):
     """GRURecurFn with h0: exercises the h0 slots, the dhn-free start and the extra dh0 pass of the backward kernel."""
     torch.set_num_threads(8)
     T, B, In = 4, 192, 12
@@ -127,7 +137,7 @@ def _run_layer(xf, x, ws, wt, ndir):
 
 
 @pytest.mark.parametrize('H', [512, 500])
-def test_persistent_equals_one_launch_per_step_bitwise_full_size(H, gemm_precision, cluster_mode):
+def test_persistent_equals_one_launch_per_step_bitwise_full_size(H, gemm_precision, cluster_mode, bptt_grid):
     """Bench-size layer (2048 trials x 20 steps, bidirectional: the per-GPU shard of configs[3]): the in-kernel
     hand-off ('persistent') and the kernel-boundary hand-off ('steps') run the same arithmetic, so EVERY output bit
     must agree -- a stale or early read of the exchange buffer shows up here.  Three launches of each (the second

@@ -14,6 +14,18 @@ bs = [(torch.randn(3 * H) * 0.1).cuda() for _ in range(ndir)]
 dy = (torch.randn(T, B, ndir * H) * 0.1).cuda()
 y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
 l = _lib.lib()
+if os.environ.get('GRID'):
+    l.xps_set_gru_bptt_grid(int(os.environ['GRID']))
+print('BPTT grid:', '4 x 4' if l.xps_get_gru_bptt_grid() else '1-D')
+ef0, ef1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
+ef0.record()
+for _ in range(10):
+    xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
+ef1.record(); torch.cuda.synchronize()
+usf = ef0.elapsed_time(ef1) / 10 * 1e3
+print(f'fwd launch (train, incl. init kernel) {usf:.1f} us ({4 * ndir * T * B * 8 * H / usf / 1e3:.0f} GB/s algorithmic)')
 l.xps_debug_gru_bwd_status_offset.restype = C.c_longlong
 off = l.xps_debug_gru_bwd_status_offset(B, H, ndir)
 wt = [torch.empty(H, 3 * H, device='cuda') for _ in ws]
@@ -40,7 +52,7 @@ if hasattr(l, 'xps_debug_read_cluster_stamps'):
     buf = (C.c_ulonglong * 16384)()
     assert l.xps_debug_read_cluster_stamps(buf, 16384) == 0
     raw = np.array(buf[:], dtype=np.float64).reshape(2048, 8)
-    slots = (T - 1) * 8 + 5
+    slots = (T - 1) * 16 + 4
     print('cycles per slot (median over workgroups): work / drain / barrier wait / poll | contraction: dma issue, mfma loop; gates: flags+math+stores, flag wait+quarter requests')
     for role, wv in (('contraction', [0, 1, 2, 3]), ('gates 5-7', [5, 6, 7]), ('gate wave 4', [4])):
         sel = np.concatenate([raw[w::8] for w in wv])
