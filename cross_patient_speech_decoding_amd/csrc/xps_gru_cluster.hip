@@ -262,6 +262,7 @@ struct ClFwd {
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
     int s_begin, s_end, handoff;
+    int saved_mm;          // saved gates member-major (H % 32 == 0), see the epilogue
 };
 
 // 512 threads, two kinds of waves; every SIMD holds one of each, so the matrix pipe never waits for a memory latency or for
@@ -512,11 +513,18 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         const unsigned yo = live ? (unsigned)((((long long)(t + 1) * B + b) * ldy + dir * H + ju) * 4) : CL_OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, yo, 0, 0);
         if (has_saved) {
-            const unsigned so = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 4 * H + ju) * 4) : CL_OOB;
+            // saved gates: private between this kernel and the BPTT kernels.  H % 32 == 0 (saved_mm): MEMBER-major --
+            // [dir][t][member][trial][gate 4][32 units] -- so that a member streams 512 contiguous bytes per trial and its trials
+            // back to back (row-major [trial][gate][H] gives it four 128-byte pieces 2 KB apart per trial: measured 8 % of the BPTT
+            // launch in DRAM page misses); otherwise [dir][t][trial][4H]
+            const unsigned gstride = p.saved_mm ? 128u : (unsigned)H * 4u;
+            const unsigned so = !live ? CL_OOB : p.saved_mm
+                ? (unsigned)((((((long long)dir * T + t) * p.CS + cm.member) * B + b) * 128 + (ju & 31)) * 4)
+                : (unsigned)(((((long long)dir * T + t) * B + b) * 4 * H + ju) * 4);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rg), sr, so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zg), sr, live ? so + (unsigned)H * 4u : CL_OOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ng), sr, live ? so + (unsigned)H * 8u : CL_OOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), sr, live ? so + (unsigned)H * 12u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zg), sr, live ? so + gstride : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ng), sr, live ? so + 2u * gstride : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), sr, live ? so + 3u * gstride : CL_OOB, 0, 0);
         }
     };
     // products of the finished round for this wave's trial tile: k-low half + k-high half, taken out of xacc
@@ -657,6 +665,7 @@ struct ClBwd {
     unsigned xbuf_bytes;
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
     int ps_begin, ps_end, ps_total, handoff;
+    int saved_mm;               // saved gates member-major (see the forward kernel's epilogue)
     int split_out;              // != 0 (bf16x3 mode): dgi / dghn are written as XPS_FMT_SPLIT4 groups (xps.h) for the GEMMs that read them
 };
 
@@ -693,7 +702,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
-    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
+    // running gradient z * dh: private to this kernel, member-major [dir][member][trial][32 units] (contiguous per member)
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * p.CS * B * 32 * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgi, 0, (unsigned)((long long)p.ndir * T * B * 3 * H * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(p.dghn, 0, (unsigned)((long long)p.ndir * T * B * H * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
@@ -726,16 +736,19 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         int nload = 0;
         in.keep = (u32x4){0u, 0u, 0u, 0u};
-        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1); ++nload; }
+        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)(((((long long)dir * p.CS + cm.member) * B + bc) * 32 + (juc & 31)) * 4), 0, AUX_SC1); ++nload; }
         else if (p.dhn) { in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc)); ++nload; }
         if (ps < T) {
             in.dy = z4;
             if (has_dy) { in.dy = *reinterpret_cast<const f32x4*>(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc); ++nload; }
-            const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+            // (layout of the saved gates: see the forward kernel's epilogue)
+            const int gs = p.saved_mm ? 32 : H;
+            const float* sv = p.saved_mm ? p.saved + ((((long long)dir * T + t) * p.CS + cm.member) * B + bc) * 128 + (juc & 31)
+                                         : p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
             in.rg = *reinterpret_cast<const f32x4*>(sv);
-            in.zg = *reinterpret_cast<const f32x4*>(sv + H);
-            in.ng = *reinterpret_cast<const f32x4*>(sv + 2 * H);
-            in.q = *reinterpret_cast<const f32x4*>(sv + 3 * H);
+            in.zg = *reinterpret_cast<const f32x4*>(sv + gs);
+            in.ng = *reinterpret_cast<const f32x4*>(sv + 2 * gs);
+            in.q = *reinterpret_cast<const f32x4*>(sv + 3 * gs);
             in.hp = *reinterpret_cast<const f32x4*>(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
             nload += 5;
         } else {
@@ -804,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)(((((long long)dir * p.CS + cm.member) * B + b) * 32 + (ju & 31)) * 4) : CL_OOB, 0, 0);
         return 5;
     };
 
@@ -1062,6 +1075,7 @@ struct ClBwd2 {
     int T, B, H, ndir, Bp, Mc, NR, nblk;
     int ps_total, handoff, do_ps0;
     int c_begin, c_end, g_begin, g_end;     // iterations whose contraction / gate math this launch runs
+    int saved_mm;               // saved gates member-major (see the forward kernel's epilogue)
     int split_out;
 };
 
@@ -1301,7 +1315,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     const int ju = jg * 128 + uo;
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
-    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * B * H * 4), RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(p.keep, 0, (unsigned)((long long)p.ndir * 16 * B * 32 * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgi, 0, (unsigned)((long long)p.ndir * T * B * 3 * H * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(p.dghn, 0, (unsigned)((long long)p.ndir * T * B * H * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.dh0, 0, p.dh0 ? (unsigned)((long long)p.ndir * B * H * 4) : 0u, RSRC_FLAGS);
@@ -1317,16 +1331,18 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         int nload = 0;
         in.keep = (u32x4){0u, 0u, 0u, 0u};
-        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)((((long long)dir * B + bc) * H + juc) * 4), 0, AUX_SC1); ++nload; }
+        if (ps > 0) { in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)(((((long long)dir * 16 + cm.member) * B + bc) * 32 + (juc & 31)) * 4), 0, AUX_SC1); ++nload; }
         else if (p.dhn) { in.keep = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.dhn + ((long long)dir * B + bc) * H + juc)); ++nload; }
         if (ps < T) {
             in.dy = z4;
             if (has_dy) { in.dy = CL2_STREAM_LOAD(p.dy + ((long long)t * B + bc) * ldy + dir * H + juc); ++nload; }
-            const float* sv = p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+            const int gs = p.saved_mm ? 32 : H;
+            const float* sv = p.saved_mm ? p.saved + ((((long long)dir * T + t) * ((H + 31) / 32) + cm.member) * B + bc) * 128 + (juc & 31)
+                                         : p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
             in.rg = CL2_STREAM_LOAD(sv);
-            in.zg = CL2_STREAM_LOAD(sv + H);
-            in.ng = CL2_STREAM_LOAD(sv + 2 * H);
-            in.q = CL2_STREAM_LOAD(sv + 3 * H);
+            in.zg = CL2_STREAM_LOAD(sv + gs);
+            in.ng = CL2_STREAM_LOAD(sv + 2 * gs);
+            in.q = CL2_STREAM_LOAD(sv + 3 * gs);
             in.hp = CL2_STREAM_LOAD(p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc);
             nload += 5;
         } else {
@@ -1389,7 +1405,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, CL2_AUX_STREAM);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, CL2_AUX_STREAM);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)(((((long long)dir * 16 + cm.member) * B + b) * 32 + (ju & 31)) * 4) : CL_OOB, 0, 0);
     };
 
     if (p.do_ps0) {
@@ -1569,7 +1585,7 @@ ClPlan cl_plan(int B, int H, int ndir) {
     pl.flags_bytes = (((size_t)ndir * pl.nblk * (pl.NR + 1) * 16 * 4 + 256 + 255) / 256) * 256;
     pl.xbuf_fwd = (size_t)2 * ndir * pl.Bp * pl.KP * 4;
     pl.xbuf_bwd = 3 * pl.xbuf_fwd;
-    pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
+    pl.keep_bytes = (((size_t)ndir * B * pl.CS * 32 * 4 + 255) / 256) * 256;
     pl.ok = pl.NR >= 6 && pl.xbuf_bwd < ((size_t)1 << 31);
     return pl;
 }
@@ -1609,7 +1625,7 @@ ClPlan2 cl_plan2(int B, int H, int ndir) {
     pl.grid = ndir * pl.nblk * 16;
     // header: flags [cluster][NR][160], XCC table [cluster][16], padding, status block (last 256 B); zeroed before every launch
     pl.flags_bytes = (((size_t)ndir * pl.nblk * (pl.NR * 160 + 16) * 4 + 256 + 255) / 256) * 256;
-    pl.keep_bytes = (((size_t)ndir * B * H * 4 + 255) / 256) * 256;
+    pl.keep_bytes = (((size_t)ndir * B * 16 * 32 * 4 + 255) / 256) * 256;
     pl.xbuf = (size_t)2 * ndir * (pl.Bp / C2_RT) * 4 * C2_IMG;
     pl.pbuf = (size_t)2 * ndir * pl.nblk * pl.NR * 64 * 2048;
     pl.ok = pl.xbuf < ((size_t)1 << 31) && pl.pbuf < ((size_t)1 << 32);
@@ -1696,6 +1712,7 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
     p.xbuf = ws + pl.flags_bytes;
     p.xbuf_bytes = (unsigned)pl.xbuf_fwd;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.Bp = pl.Bp; p.Mc = pl.Mc; p.NR = pl.NR; p.nblk = pl.nblk; p.CS = pl.CS;
+    p.saved_mm = (H % 32 == 0) ? 1 : 0;
     if (hipMemsetAsync(ws, 0, pl.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster forward: memset failed"); return XPS_E_HIP; }
     if (pl.CS * pl.U < pl.KP) {
         // state columns no member owns (H far below KP) meet zero weights in the contraction: they must be finite
@@ -1760,6 +1777,7 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
         q.xbuf_bytes = (unsigned)p2.xbuf;
         q.pbuf_bytes = (unsigned)p2.pbuf;
         q.T = T; q.B = B; q.H = H; q.ndir = ndir; q.Bp = p2.Bp; q.Mc = p2.Mc; q.NR = p2.NR; q.nblk = p2.nblk;
+        q.saved_mm = (H % 32 == 0) ? 1 : 0;
         if (hipMemsetAsync(ws, 0, p2.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster backward: memset failed"); return XPS_E_HIP; }
         const int ps_total = T + (dh0 ? 1 : 0);
         q.ps_total = ps_total;
@@ -1802,6 +1820,7 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     p.xbuf = ws + pl.flags_bytes + pl.keep_bytes;
     p.xbuf_bytes = (unsigned)pl.xbuf_bwd;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.Bp = pl.Bp; p.Mc = pl.Mc; p.NR = pl.NR; p.nblk = pl.nblk; p.CS = pl.CS;
+    p.saved_mm = (H % 32 == 0) ? 1 : 0;
     if (hipMemsetAsync(ws, 0, pl.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster backward: memset failed"); return XPS_E_HIP; }
     if (pl.CS * pl.U < pl.KP) {
         // gate-gradient columns no member owns (H far below KP) are contracted with zero weights: they must be finite

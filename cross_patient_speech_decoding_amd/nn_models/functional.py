@@ -279,8 +279,8 @@ _gru_ws_cache = {}
 
 
 def _gru_ws_bytes(fn, T, B, H, ndir):
-    """Workspace size of the recurrence entry points (depends on the shape and on the cluster mode only)."""
-    key = (fn, T, B, H, ndir, lib().xps_get_gru_cluster_mode())
+    """Workspace size of the recurrence entry points (depends on the shape, the cluster mode and the BPTT grid only)."""
+    key = (fn, T, B, H, ndir, lib().xps_get_gru_cluster_mode(), lib().xps_get_gru_bptt_grid())
     n = _gru_ws_cache.get(key)
     if n is None:
         n = getattr(lib(), fn)(T, B, H, ndir)

@@ -141,7 +141,9 @@ int xps_colsum_f32(const float* X, int64_t ldx, int rows, int cols, float* out, 
 /*   y_ext [T+2][B][ndir*H]  slot t+1 holds h_t of every direction in ACTUAL     */
 /*          time; slot 0 / slot T+1 hold h0 of the forward / reverse direction;  */
 /*          direction 1 runs t = T-1 .. 0                                       */
-/*   saved [ndir][T][B][4H]  r, z, n, (W_hn h + b_hn) for the backward (or NULL)  */
+/*   saved ndir*T*B*4H floats: r, z, n, (W_hn h + b_hn) for the backward (or NULL).  OPAQUE: written by the forward entry point and
+ *          read by the backward entry point of the same shape and mode only; [ndir][T][B][4H] on most paths, member-major
+ *          ([ndir][T][H/32][B][4][32]) on the cluster path when H % 32 == 0 (sequential HBM streams per workgroup)            */
 /* ------------------------------------------------------------------------- */
 /* 128 < H <= 512 (H % 4 == 0, B >= 128): cluster-persistent recurrence (csrc/xps_gru_cluster.hip): W_hh stays in the registers
  * of a cluster of workgroups for the whole sequence, the members exchange h_t through `workspace` inside ONE launch.
