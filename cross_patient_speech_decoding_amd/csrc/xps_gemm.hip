@@ -720,13 +720,18 @@ std::atomic<int>& gemm_mode() {
 inline bool bf_mode() { return gemm_mode().load(std::memory_order_relaxed) == 1; }
 
 // 64-row tiles when 128-row tiles would leave the chip under-filled (< ~2 blocks per CU)
-inline bool use_small_tiles(int M, int N) {
+// (long contractions -- the rows a 256-tile launch leaves behind, K >= 1024 -- are issue-bound, not HBM-bound: there the 128-row
+//  tile's better MFMA-per-staged-element ratio wins as soon as every CU gets two blocks)
+inline bool use_small_tiles(int M, int N, int K = 0) {
     static const int thr = [] {
         const char* e = getenv("XPS_GEMM_SMALL_TILE_BLOCKS");
         int v = e ? atoi(e) : -1;
         return v >= 0 ? v : 2048;
     }();
-    return M > 64 && (long long)cdiv(M, 128) * cdiv(N, BN) < thr;
+    const long long n128 = (long long)cdiv(M, 128) * cdiv(N, BN);
+    static const bool longk = [] { const char* e = getenv("XPS_GEMM_LONGK_128"); return !(e && e[0] == '0'); }();
+    if (longk && K >= 1024 && n128 >= 512) return false;
+    return M > 64 && n128 < thr;
 }
 
 // 256 x 256 tiles (xps_gemm_big.h): bf16 split-product mode, whole tiles only, plain 16-byte aligned operands, and
@@ -847,7 +852,7 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
                                bias, M, N, K, kchunk, 0LL, accumulate, vecA, vecB);                                   \
     } while (0)
     const bool bf = bf_mode();
-    if (use_small_tiles(M, N)) {
+    if (use_small_tiles(M, N, K + K2)) {
         dim3 grid(cdiv(N, BN) * cdiv(M, 64));
         const bool edge = (M % 64) || (N % BN);
         if (bf) { if (edge) XPS_LAUNCH_GEMM(1, true, true); else XPS_LAUNCH_GEMM(1, false, true); }
@@ -995,7 +1000,7 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
                                (hipStream_t)stream, A, ra, pm, rb, rc, M, N, K, nprob, vecA, vecB);                        \
     } while (0)
     const bool bf = bf_mode();
-    if (use_small_tiles(M, N * nprob)) {
+    if (use_small_tiles(M, N * nprob, K)) {
         const bool edge = (M % 64) || (N % BN);
         if (bf) { if (edge) XPS_LAUNCH_NTM(1, true, true); else XPS_LAUNCH_NTM(1, false, true); }
         else { if (edge) XPS_LAUNCH_NTM(1, true, false); else XPS_LAUNCH_NTM(1, false, false); }

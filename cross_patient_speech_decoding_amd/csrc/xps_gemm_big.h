@@ -90,6 +90,7 @@ __device__ inline void big_pipeline_t(f32x16 (&acc)[4][2], f32x4& csum, const bo
         const int buf = kt & 1;
         if (kt + 2 < nkt) { la.load(ra0, kt + 2); lb.load(rb0, kt + 2); }
         {
+#ifndef XPS_BIG_PIN      // (pinned A-fragment prefetch measured: within 1 % on every shape of tools/bench_gemm_h512.py -- not the default)
             bf16x8 bh[2], bl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf_frag<BK, 256>(S.b[buf], wn + j * 32, lane, bh[j], bl[j]);
@@ -104,6 +105,28 @@ __device__ inline void big_pipeline_t(f32x16 (&acc)[4][2], f32x4& csum, const bo
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
             }
+#else
+            // The A fragment of row group i + 1 is requested BEFORE the six MFMAs of row group i (two register sets, pinned with
+            // scheduling barriers): left alone the scheduler requests it after four of them and waits for it behind the sixth -- two
+            // MFMAs (64 cycles) of cover for an LDS read, four times per k-tile on both waves of a SIMD at once.
+            bf16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf_frag<BK, 256>(S.b[buf], wn + j * 32, lane, bh[j], bl[j]);
+            bf_frag<AK, 256>(S.a[buf], wm, lane, ah[0], al[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i + 1 < 4) bf_frag<AK, 256>(S.a[buf], wm + (i + 1) * 32, lane, ah[(i + 1) & 1], al[(i + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
         if (kt + 1 < nkt) {
             big_stage<AK>(ra1, S.a[buf ^ 1], tid, preA);
