@@ -419,6 +419,16 @@ int xps_process_hg_f64(const double* data, int C, int Tn, const uint8_t* good, c
 int xps_apply_f64(const void* X, int x_is_f32, int64_t ldx, const double* mean, const double* W,
                   int64_t ldw, void* Y, int y_is_f32, int64_t ldy, int64_t n, int d_in, int d_out,
                   void* stream);
+/* Batched C-SVC training on a precomputed kernel matrix (config-1 decode path: the one-vs-one linear SVMs sklearn's
+ * SVC(kernel='linear') trains through libsvm; reference call sites decoders/cross_pt_decoders.py:29-38, scripts/aligned_decode_svm.py:262-263).
+ * K: n_all x n_all kernel (Gram) matrix, float64, leading dimension ldk.  Problem p: the points idx[off[p] .. off[p+1]) of K, the
+ * first npos[p] with label +1, the rest -1 (libsvm's binary sub-problem of a class pair).  One workgroup per problem runs libsvm's
+ * SMO (WSS 2, eps stopping rule, calculate_rho) with alpha / gradient in LDS (max_points = the largest problem, at most
+ * xps_svm_smo_f64_max_points()); cbound[off[p] + t] = the point's upper bound C * sample_weight (> 0: libsvm drops zero-weight
+ * points before training, so does the caller).  Outputs: alpha[off[p] + t], rho[p], iterations[p].                          */
+size_t xps_svm_smo_f64_max_points(void);
+int xps_svm_smo_f64(const double* K, int64_t ldk, const int* idx, const int* off, const int* npos, int nprob, int max_points,
+                    const double* cbound, double eps, int max_iter, double* alpha, double* rho, int* iterations, void* stream);
 /* small dense float64 GEMM  C = op(A) op(B)  (row-major, op = transpose flag) */
 int xps_dgemm_small(const double* A, int64_t lda, int ta, const double* B, int64_t ldb, int tb,
                     double* C, int64_t ldc, int M, int N, int K, void* stream);

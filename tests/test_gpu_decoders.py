@@ -12,7 +12,12 @@ from sklearn.svm import SVC
 pytestmark = pytest.mark.gpu
 
 
-def svm():
+def svm(device=False):
+    """The reference's decoder (scripts/aligned_decode_svm.py:262-263): ten bagged linear SVMs.  device=True: the same bagging around
+    the HIP SVC (decoders/svm.py) instead of sklearn's libsvm wrapper -- sklearn draws the same bootstrap samples either way."""
+    if device:
+        from cross_patient_speech_decoding_amd.decoders import SVC as DeviceSVC
+        return BaggingClassifier(DeviceSVC(kernel='linear'), n_estimators=10, random_state=0)
     return BaggingClassifier(SVC(kernel='linear'), n_estimators=10, random_state=0)
 
 
@@ -31,8 +36,9 @@ def _close_up_to_sign_per_latent(X, ref, T, tol):
     assert np.abs(X - ref).max() <= tol * np.abs(ref).max()
 
 
+@pytest.mark.parametrize('device_svm', [False, True], ids=['sklearn-svm', 'hip-svm'])
 @pytest.mark.parametrize('name', ['sepAlign', 'sepDimRed', 'jointDimRed'])
-def test_config1_decoders_match_reference(golden_dir, name):
+def test_config1_decoders_match_reference(golden_dir, name, device_svm):
     import cross_patient_speech_decoding_amd.alignment as A
     from cross_patient_speech_decoding_amd.decoders import (crossPtDecoder_jointDimRed, crossPtDecoder_sepAlign,
                                                             crossPtDecoder_sepDimRed)
@@ -41,11 +47,11 @@ def test_config1_decoders_match_reference(golden_dir, name):
     y1 = yt[:, 0]
     tr, te = g['train_idx'], g['test_idx']
     if name == 'sepAlign':
-        dec = crossPtDecoder_sepAlign(cross, svm(), A.AlignCCA, n_comp=0.9)
+        dec = crossPtDecoder_sepAlign(cross, svm(device_svm), A.AlignCCA, n_comp=0.9)
     elif name == 'sepDimRed':
-        dec = crossPtDecoder_sepDimRed(cross, svm(), n_comp=0.9)
+        dec = crossPtDecoder_sepDimRed(cross, svm(device_svm), n_comp=0.9)
     else:
-        dec = crossPtDecoder_jointDimRed(cross, svm(), A.JointPCA, n_comp=6)
+        dec = crossPtDecoder_jointDimRed(cross, svm(device_svm), A.JointPCA, n_comp=6)
     clone(dec)                                                    # constructor args stored verbatim
     kw = {} if name == 'sepDimRed' else {'y_align': yt[tr]}
     dec.fit(Xt[tr], y1[tr], **kw)
@@ -81,3 +87,39 @@ def test_mcca_decoder_and_nocenter_pca():
         NoCenterPCA(3).transform(X)
     z = DimRedReshape(A.PCA, n_components=4).fit_transform(Xt)
     assert z.shape == (Xt.shape[0], 4)
+
+
+@pytest.mark.parametrize('n,d,k,C', [(120, 10, 2, 1.0), (300, 40, 5, 1.0), (500, 140, 9, 0.3), (64, 6, 3, 10.0)])
+def test_hip_svc_equals_libsvm(n, d, k, C):
+    """The HIP SVC against sklearn's SVC(kernel='linear') (libsvm, what the reference calls): same one-vs-one decision values to the
+    solvers' tolerance (both stop at a maximal KKT violation of tol = 1e-3), identical predictions wherever the vote is not decided
+    by a decision value inside that tolerance, same accuracy; overlapping classes (bounded and free support vectors), imbalanced
+    class sizes, labels that are not 0..k-1."""
+    from cross_patient_speech_decoding_amd.decoders import SVC as DeviceSVC
+    rng = np.random.default_rng(n + d)
+    centers = rng.standard_normal((k, d)) * 1.2
+    sizes = rng.multinomial(n - 4 * k, np.ones(k) / k) + 4
+    X = np.vstack([centers[c] + rng.standard_normal((m, d)) for c, m in enumerate(sizes)])
+    y = np.repeat(np.arange(k) * 3 + 1, sizes)
+    perm = rng.permutation(len(y))
+    X, y = X[perm], y[perm]
+    Xte = np.vstack([centers[c] + rng.standard_normal((20, d)) for c in range(k)])
+    ref = SVC(kernel='linear', C=C, decision_function_shape='ovo').fit(X, y)
+    dev = DeviceSVC(kernel='linear', C=C).fit(X, y)
+    np.testing.assert_array_equal(dev.classes_, ref.classes_)
+    d_ref = ref.decision_function(Xte)
+    d_dev = dev.decision_function(Xte)
+    scale = max(1.0, float(np.abs(d_ref).max()))
+    assert d_dev.shape == d_ref.shape
+    assert np.abs(d_dev - d_ref).max() <= 2e-2 * scale, np.abs(d_dev - d_ref).max()       # two tol = 1e-3 solutions of one problem
+    p_ref, p_dev = ref.predict(Xte), dev.predict(Xte)
+    sure = np.abs(d_ref if d_ref.ndim == 2 else d_ref[:, None]).min(axis=1) > 5e-2 * scale
+    np.testing.assert_array_equal(p_dev[sure], p_ref[sure])
+    assert np.mean(p_dev == p_ref) >= 0.97
+    assert abs(dev.score(Xte, np.repeat(np.arange(k) * 3 + 1, 20)) - ref.score(Xte, np.repeat(np.arange(k) * 3 + 1, 20))) <= 0.03
+    # bagging / cloning / parameter plumbing as the reference's scripts use it
+    bag = BaggingClassifier(clone(DeviceSVC(kernel='linear', C=C)), n_estimators=3, random_state=1).fit(X, y)
+    assert bag.predict(Xte).shape == (20 * k,)
+    assert DeviceSVC().set_params(C=2.0).get_params()['C'] == 2.0
+    with pytest.raises(NotImplementedError):
+        DeviceSVC(kernel='rbf').fit(X, y)
