@@ -146,6 +146,8 @@ def _low_priority_stream(idx):
     """Side stream BELOW the default priority (torch only offers default / high): when a CU frees up, kernels of
     the critical path are dispatched first; measured without it, tiny main-stream kernels queued up to 100 us
     behind the side stream's GEMM blocks."""
+    if os.environ.get('XPS_SIDE_PRIORITY') == 'default':       # (diagnostic: tools/graph_probe.py -- what a hipGraph replay does to the side work)
+        return torch.cuda.Stream(device=idx)
     handle = C.c_void_p()
     with torch.cuda.device(idx):
         call('xps_stream_create_low_priority', C.byref(handle))

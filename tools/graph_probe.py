@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
-c = bench.CFG
+c = bench.WORKLOADS[os.environ.get('WORKLOAD', 'configs1')]
 torch.manual_seed(1234)
 model = bench.build_model(c).cuda()
 opt = FlatAdamW(model, lr=1e-4, weight_decay=1e-5, max_norm=0.5)
@@ -21,13 +21,14 @@ def step():
     loss.backward(one)
     opt.step()
     return loss
-for _ in range(400): step()
+for _ in range(int(os.environ.get('PREWARM', '400'))): step()
 torch.cuda.synchronize()
 def timeit(fn, n=50):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-print(f'eager   {timeit(step):.3f} ms/step', flush=True)
+N_T = int(os.environ.get('NT', '50'))
+print(f'eager   {timeit(step, N_T):.3f} ms/step', flush=True)
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
@@ -39,5 +40,5 @@ with torch.cuda.graph(g):
     loss = step()
 torch.cuda.synchronize()
 for _ in range(20): g.replay()
-print(f'graphed {timeit(g.replay):.3f} ms/step   loss {float(loss):.4f}', flush=True)
-print(f'eager   {timeit(step):.3f} ms/step', flush=True)
+print(f'graphed {timeit(g.replay, N_T):.3f} ms/step   loss {float(loss):.4f}', flush=True)
+print(f'eager   {timeit(step, N_T):.3f} ms/step', flush=True)
