@@ -20,9 +20,10 @@ using namespace xps_tile;
 
 constexpr int TM = 256, TN = 256, NTHR = 512;
 
+constexpr int BIG_NS = 2;
 struct BigStage {
-    BfTile<256> a[2];
-    BfTile<256> b[2];
+    BfTile<256> a[BIG_NS];
+    BfTile<256> b[BIG_NS];
 };
 
 // thread -> two 16-byte vectors of a 256 x 16 k-tile.  KC ([x][k]): row x = tid / 4 + 128 r, k = 4 (tid % 4);
@@ -88,7 +89,9 @@ __device__ inline void big_pipeline_t(f32x16 (&acc)[4][2], f32x4& csum, const bo
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+#ifndef XPS_BIG_ABL_NOLOAD        // (timing ablation, wrong results: the k loop without its global loads)
         if (kt + 2 < nkt) { la.load(ra0, kt + 2); lb.load(rb0, kt + 2); }
+#endif
         {
 #ifndef XPS_BIG_PIN      // (pinned A-fragment prefetch measured: within 1 % on every shape of tools/bench_gemm_h512.py -- not the default)
             bf16x8 bh[2], bl[2];
@@ -129,13 +132,17 @@ __device__ inline void big_pipeline_t(f32x16 (&acc)[4][2], f32x4& csum, const bo
 #endif
         }
         if (kt + 1 < nkt) {
+#ifndef XPS_BIG_ABL_NOSTAGE       // (timing ablation, wrong results: no LDS stores of the next k-tile)
             big_stage<AK>(ra1, S.a[buf ^ 1], tid, preA);
             big_stage<BK>(rb1, S.b[buf ^ 1], tid, preB);
+#endif
             if (!AK && want_csum) csum += stage_values(ra1[0], preA) + stage_values(ra1[1], preA);
 #pragma unroll
             for (int r = 0; r < 2; ++r) { ra1[r] = ra0[r]; rb1[r] = rb0[r]; }
         }
+#ifndef XPS_BIG_ABL_NOBARRIER      // (timing ablation, wrong results: no barrier per k-tile)
         __syncthreads();
+#endif
     }
 }
 
