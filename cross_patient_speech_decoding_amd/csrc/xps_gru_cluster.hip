@@ -1561,7 +1561,11 @@ ClPlan cl_plan(int B, int H, int ndir) {
     ClPlan pl;
     memset(&pl, 0, sizeof(pl));
     if (cl_mode() == 0 || H <= 256 || H > 512 || (H % 4) != 0 || B < 128) return pl;
-    const int cus = cl_num_cus();
+    int cus = cl_num_cus();
+    {   // diagnostic: plan for fewer CUs than the device has (how the launch time scales with the CUs that take part: DESIGN.md 4.5)
+        static const int cap = [] { const char* e = getenv("XPS_GRU_CL_CUS"); return e ? atoi(e) : 0; }();
+        if (cap > 0 && cap < cus) cus = cap;
+    }
     pl.KSPLIT = H > 256 ? 2 : 1;
     pl.KP = 256 * pl.KSPLIT;
     pl.U = 64 / pl.KSPLIT;

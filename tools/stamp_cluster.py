@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cross_patient_speech_decoding_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libxps_clstamp.so')
+_lib.LIB_PATH = os.environ.get('XPS_STAMP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libxps_clstamp.so')
 from cross_patient_speech_decoding_amd.nn_models import functional as xf
 T, B, H, ndir = 20, 2048, 512, 2
 torch.manual_seed(0)
