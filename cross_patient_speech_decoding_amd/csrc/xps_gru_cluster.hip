@@ -13,9 +13,11 @@
 //             LDS image.
 //   waves   : 0-3 contract (wave (ut, kh): 16 units x 3 gates x 256 k; 144 MFMAs per round: v_mfma_f32_16x16x32_bf16
 //             on split operands lo*hi + hi*lo + hi*hi, fp32 mode 16x16x4 f32) and hand the products over through LDS;
-//             4-7 sum the k-halves, run the gate math of one (unit tile, trial tile) each, store outputs and exchange
-//             planes, prefetch the gate inputs two rounds ahead, publish flags (and, forward, issue the DMA pieces).
-//             Lane (n, kq) owns trial n and FOUR CONSECUTIVE units: every global access is a 16-byte vector.
+//             4-7 sum the k-halves, run the gate math of 8 trials x the member's 32 units each, store outputs and exchange
+//             planes, prefetch the gate inputs two rounds ahead, publish flags.
+//             Gate-wave lane (t8, uq) owns trial 8 w + t8 of the round and FOUR CONSECUTIVE units 4 uq .. 4 uq + 3: every
+//             global access is a 16-byte vector and a wave-instruction covers eight FULL 128-byte lines of its stream
+//             (a 16-unit x 16-trial tile per wave touched sixteen half lines: BPTT launch 909 -> 808 us, forward 633 -> 604).
 //
 // Hand-off protocol (MI355X_MICROARCH.md "Valid forms", first table row; cdna_hip_programming.md G16 R1):
 // exchanged bytes are loaded with sc1 (L1 bypass) and stored write-through (sc1) -- or with plain write-back
@@ -74,6 +76,7 @@ struct ClCfg {
 // Diagnostic build only (tools/stamp_cluster.py; never shipped): per-wave cycle sums of the loop segments, written to a
 // buffer of their own that no kernel reads.
 __device__ unsigned long long g_clstamp[2048 * 8];
+__device__ unsigned long long g_clstamp2[2048 * 8];   // second set: phases inside the gate waves' slots (2-D BPTT kernel)
 #define CL_STAMP(var)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
@@ -408,8 +411,11 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             // the previous round's products must have been taken out of xacc (they were, two thousand cycles ago: one look)
             if (it > it_begin) {
                 const unsigned want = (unsigned)(it - it_begin);
-                while (__hip_atomic_load(consumed + 2 * ut, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
-                       __hip_atomic_load(consumed + 2 * ut + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+                // (every gate wave takes units of both unit tiles)
+                while (__hip_atomic_load(consumed + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
+                       __hip_atomic_load(consumed + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
+                       __hip_atomic_load(consumed + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want ||
+                       __hip_atomic_load(consumed + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
                     __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -437,9 +443,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     // MFMAs.  With priority the gate wave's instructions go first whenever it has one, the MFMAs fill the rest.
     __builtin_amdgcn_s_setprio(3);
     const int hw = wave - 4;
-    const int hut = hw >> 1, te = hw & 1;              // unit tile, trial tile of the round
-    const int j0 = cm.member * Cf::U + hut * 16;
-    const int ju = j0 + 4 * kq;                        // this lane's four units
+    // lane (t8, uq): trial 8 hw + t8 of the round's 32, units 4 uq .. 4 uq + 3 of the member's 32 (see the BPTT kernel)
+    const int gtr = 8 * hw + (lane >> 3);
+    const int guq = lane & 7;
+    const int ju = cm.member * Cf::U + 4 * guq;
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
     const float* __restrict__ gi = p.gi + (long long)dir * T * B * 3 * H;
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     auto epi_load = [&](int sn, int rn, EpiIn& in) {      // 4 loads, always issued
         const int t = (dir == 0) ? sn : T - 1 - sn;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int b = m_base + 32 * rn + 16 * te + n;
+        const int b = m_base + 32 * rn + gtr;
         const int bc = b < B ? b : B - 1;
         const float* gp = gi + ((long long)t * B + bc) * 3 * H + juc;
 #ifdef XPS_CL_ABL_NOLOAD
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     // ALWAYS issued (dead lanes: offset out of range, dropped)
     auto epilogue = [&](int sn, int rn, const EpiIn& in, const f32x4 (&a)[3]) {
         const int t = (dir == 0) ? sn : T - 1 - sn;
-        const int b = m_base + 32 * rn + 16 * te + n;
+        const int b = m_base + 32 * rn + gtr;
         const bool live = b < B && ulive;
         const f32x4 hp = __builtin_bit_cast(f32x4, in.hp);      // (whole vector: a bit_cast of ONE element reads element 0)
         f32x4 o, rg, zg, ng, qv;
@@ -532,8 +539,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     auto take_products = [&](int rounds_done) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut) * 2 + te) * 3 + g) * 1024 + lane * 16);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * hut + 1) * 2 + te) * 3 + g) * 1024 + lane * 16);
+            const int ut_ = guq >> 2, te_ = gtr >> 4, lo_ = ((guq & 3) * 16 + (gtr & 15)) * 16;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xacc + (((2 * ut_) * 2 + te_) * 3 + g) * 1024 + lo_);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(xacc + (((2 * ut_ + 1) * 2 + te_) * 3 + g) * 1024 + lo_);
             prod[g] = lo + hi;
         }
         // the reads above must have returned before the contraction waves may overwrite xacc
@@ -697,8 +705,11 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
 
     // gate waves: unit tile, trial tile, units, buffers
     const int hw = wave >= 4 ? wave - 4 : 0;
-    const int hut = hw >> 1, te = hw & 1;
-    const int ju = cm.member * Cf::U + hut * 16 + 4 * kq;
+    // gate-wave lane (t8, uq): trial 8 hw + t8 of the round's 32, units 4 uq .. 4 uq + 3 of the member's 32: a wave-instruction
+    // covers 8 trials x 32 units = eight FULL 128-byte lines of every stream (a 16-unit tile per wave touched sixteen half lines)
+    const int gtr = 8 * hw + (lane >> 3);
+    const int guq = lane & 7;
+    const int ju = cm.member * Cf::U + 4 * guq;
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int b = m_base + 32 * r + 16 * te + n;
+        const int b = m_base + 32 * r + gtr;
         const int bc = b < B ? b : B - 1;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         int nload = 0;
@@ -762,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) -> int {
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
-        const int b = m_base + 32 * r + 16 * te + n;
+        const int b = m_base + 32 * r + gtr;
         const bool live = b < B && ulive;
         f32x4 carry = __builtin_bit_cast(f32x4, in.keep);             // (whole vector: a bit_cast of ONE element reads element 0)
         if (ps > 0) carry += acc;
@@ -786,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         }
         if (ps + 1 < p.ps_total) {                      // someone will contract these gradients
             const unsigned chunk0 = (unsigned)((((ps & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r) * 3);
-            const unsigned rowoff = (unsigned)(16 * te + n) * (unsigned)(KP * 4);
+            const unsigned rowoff = (unsigned)gtr * (unsigned)(KP * 4);
             const f32x4* gsrc[3] = {&dar, &daz, &danr};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -950,9 +961,11 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     EpiIn ein;
     int pend_ps = -1, pend_r = 0;    // round whose contraction is complete and whose gate math is due
     auto finish = [&](int qlast) -> int {   // qlast: the g == 2 sub-iteration of the pending round; returns the group-C stores
-        const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + lane * 16;
-        f32x4 a = *reinterpret_cast<const f32x4*>(xa + ((2 * hut) * 2 + te) * 1024);
-        a += *reinterpret_cast<const f32x4*>(xa + ((2 * hut + 1) * 2 + te) * 1024);
+        // products of contraction wave (ut, kh), trial tile te: 1 KiB, lane (n, kq) of the MFMA layout at (16 kq + n) x 16 B
+        const int ut_ = guq >> 2, te_ = gtr >> 4;
+        const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + (((guq & 3) * 16 + (gtr & 15)) * 16);
+        f32x4 a = *reinterpret_cast<const f32x4*>(xa + ((2 * ut_) * 2 + te_) * 1024);
+        a += *reinterpret_cast<const f32x4*>(xa + ((2 * ut_ + 1) * 2 + te_) * 1024);
         return epilogue(pend_ps, pend_r, ein, a);
     };
     {
@@ -1311,7 +1324,12 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     __builtin_amdgcn_s_setprio(3);
     const int hw = wave - 4;
     const int pair = hw >> 1, hut = hw & 1;               // pair: takes the iterations i with i % 2 == pair; unit tile
-    const int uo = kg * 32 + hut * 16 + 4 * kq;           // this lane's four units inside group jg
+    // lane (t8, uq): trial 8 hut + t8 of the round's 16, units 4 uq .. 4 uq + 3 of the member's 32: eight full 128-byte lines per
+    // wave-instruction on every stream (see the 1-D kernel)
+    const int gtr = 8 * hut + (lane >> 3);
+    const int guq = lane & 7;
+    const int uo = kg * 32 + 4 * guq;
+    const unsigned qtile = (unsigned)((((guq >> 2) * 64) + (guq & 3) * 16 + gtr) * 16);    // this lane's products inside a quarter tile
     const int ju = jg * 128 + uo;
     const bool ulive = ju < H;
     const int juc = ulive ? ju : 0;
@@ -1326,7 +1344,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
         const int s_ = T - 1 - ps;
         const int t = (dir == 0) ? s_ : T - 1 - s_;
         const int slot_prev = (dir == 0) ? t : t + 2;
-        const int b = m_base + C2_RT * r + n;
+        const int b = m_base + C2_RT * r + gtr;
         const int bc = b < B ? b : B - 1;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         int nload = 0;
@@ -1355,7 +1373,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) {
         const int s_ = T - 1 - ps;
         const int t = (dir == 0) ? s_ : T - 1 - s_;
-        const int b = m_base + C2_RT * r + n;
+        const int b = m_base + C2_RT * r + gtr;
         const bool live = b < B && ulive;
         f32x4 carry = __builtin_bit_cast(f32x4, in.keep);
         if (ps > 0) carry += acc;
@@ -1380,7 +1398,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
         if (ps + 1 < p.ps_total) {                      // someone will contract these gradients: slice jg of round r
             // row of trial n, plane-row byte L = 2 (128 g + uo) -> 16-byte chunk (L >> 4) ^ n of its 256-byte window (the operand
             // image's bank swizzle, see the kernel header), byte L & 15 inside the chunk
-            const unsigned base = x_chunk(ps, r, jg) + (unsigned)n * 1536u;
+            const unsigned base = x_chunk(ps, r, jg) + (unsigned)gtr * 1536u;
             const unsigned Lq = (unsigned)uo >> 3, Lw = ((unsigned)uo & 4u) << 1;
             const f32x4* gsrc[3] = {&dar, &daz, &danr};
 #pragma unroll
@@ -1388,7 +1406,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
                 bf16x4 sh, sl;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { __bf16 a_, c_; bf_split((*gsrc[g])[i], a_, c_); sh[i] = a_; sl[i] = c_; }
-                const unsigned o = base + ((((unsigned)(16 * g) + Lq) ^ (unsigned)n) << 4) + Lw;
+                const unsigned o = base + ((((unsigned)(16 * g) + Lq) ^ (unsigned)gtr) << 4) + Lw;
                 if (fast) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, o, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, o + 768u, 0, 0);
@@ -1443,6 +1461,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     int after_rows = 0;                                    // operations issued behind the exchange rows of the last math slot
 #ifdef XPS_CL_STAMP
     unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0, s_math = 0, s_q = 0;
+    unsigned long long sp1 = 0, sp2 = 0, s_m1 = 0, s_m2 = 0, s_m3 = 0, s_r1 = 0, s_r2 = 0, s_r3 = 0;
     CL_STAMP(sb2)
 #endif
     for (int s = s_lo; s <= s_hi; ++s) {
@@ -1455,14 +1474,22 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
             if (valid_g(s - 3)) {
                 const int i = s - 3, ps = i / NR + 1;
                 const f32x4 a = ((pq[0] + pq[1]) + pq[2]) + pq[3];
+#ifdef XPS_CL_STAMP
+                asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(ein.rg[0]), "v"(ein.q[0]), "v"(ein.hp[0]), "v"(ein.dy[0]), "v"(ein.keep[0]));
+                CL_STAMP(sp1)
+#endif
                 epilogue(ps, i % NR, ein, a);
                 younger += ps == T ? 1 : 5;
             }
+#ifdef XPS_CL_STAMP
+            else { sp1 = sb2; }
+#endif
             CL_FENCE();
+            CL_STAMP(sp2)
             if (valid_g(s - 1)) younger += epi_load((s - 1) / NR + 1, (s - 1) % NR, ein);
             after_rows = younger;
             CL_STAMP(sb3)
-            CL_ACC(s_math, sb2, sb3)
+            CL_ACC(s_math, sb2, sb3) CL_ACC(s_m1, sb2, sp1) CL_ACC(s_m2, sp1, sp2) CL_ACC(s_m3, sp2, sb3)
         } else {
             // ---- request slot ----
             if (p.handoff && valid_g(s - 4)) {
@@ -1477,10 +1504,15 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
                 }
             }
             CL_FENCE();
+            CL_STAMP(sp1)
+#ifdef XPS_CL_STAMP
+            sp2 = sp1;
+#endif
             if (valid_g(s - 2)) {
                 const int i = s - 2, ps = i / NR + 1, r = i % NR;
                 if (p.handoff) wait_flags(flag_quarters(i), true, (unsigned)ps, peek(flag_quarters(i), true), 6);
-                const unsigned tile = (unsigned)((hut * 64 + lane) * 16);
+                CL_STAMP(sp2)
+                const unsigned tile = qtile;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (p.handoff && c == kg) pq[c] = *reinterpret_cast<const f32x4*>(ownq + (i & 3) * 2048 + tile);
@@ -1488,7 +1520,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
                 }
             }
             CL_STAMP(sb3)
-            CL_ACC(s_q, sb2, sb3)
+            CL_ACC(s_q, sb2, sb3) CL_ACC(s_r1, sb2, sp1) CL_ACC(s_r2, sp1, sp2) CL_ACC(s_r3, sp2, sb3)
         }
         CL_FENCE();
         CL_STAMP(sb4)
@@ -1503,7 +1535,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
 #endif
     }
 #ifdef XPS_CL_STAMP
-    if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; g_clstamp[wid * 8 + 4] = s_math; g_clstamp[wid * 8 + 5] = s_q; }
+    if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; g_clstamp[wid * 8 + 4] = s_math; g_clstamp[wid * 8 + 5] = s_q;
+                      g_clstamp2[wid * 8 + 0] = s_m1; g_clstamp2[wid * 8 + 1] = s_m2; g_clstamp2[wid * 8 + 2] = s_m3; g_clstamp2[wid * 8 + 3] = s_r1; g_clstamp2[wid * 8 + 4] = s_r2; g_clstamp2[wid * 8 + 5] = s_r3; }
 #endif
 }
 
@@ -1864,6 +1897,9 @@ extern "C" long long xps_debug_gru_bwd_status_offset(int B, int H, int ndir) {
 }
 
 #ifdef XPS_CL_STAMP
+extern "C" int xps_debug_read_cluster_stamps2(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clstamp2), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
 extern "C" int xps_debug_read_cluster_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clstamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
 }

@@ -57,3 +57,13 @@ if hasattr(l, 'xps_debug_read_cluster_stamps'):
     for role, wv in (('contraction', [0, 1, 2, 3]), ('gates 5-7', [5, 6, 7]), ('gate wave 4', [4])):
         sel = np.concatenate([raw[w::8] for w in wv])
         print(f'   {role:12s} {np.median(sel[:, 0]) / slots:8.0f} {np.median(sel[:, 1]) / slots:8.0f} {np.median(sel[:, 2]) / slots:8.0f} {np.median(sel[:, 3]) / slots:8.0f} | {np.median(sel[:, 4]) / slots:8.0f} {np.median(sel[:, 5]) / slots:8.0f}')
+
+    if hasattr(l, 'xps_debug_read_cluster_stamps2') and l.xps_get_gru_bptt_grid():
+        l.xps_debug_read_cluster_stamps2.argtypes = [C.c_void_p, C.c_int]
+        assert l.xps_debug_read_cluster_stamps2(buf, 16384) == 0
+        raw = np.array(buf[:], dtype=np.float64).reshape(2048, 8)
+        pairs = slots / 2
+        print('gate waves, cycles per (math slot + request slot): math slot: until inputs are there / epilogue issued / next inputs requested | request slot: exchange-row wait + flag / quarter flags / quarters requested')
+        for role, wv in (('gates 5-7', [5, 6, 7]), ('gate wave 4', [4])):
+            sel = np.concatenate([raw[w::8] for w in wv])
+            print(f'   {role:12s} ' + ' '.join(f'{np.median(sel[:, k]) / pairs:8.0f}' for k in range(6)))
