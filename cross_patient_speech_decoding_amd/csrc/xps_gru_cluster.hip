@@ -767,17 +767,51 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         }
         return nload;
     };
+    // The same for the main loop, WITHOUT a branch around any load (LD = 1: a step ps in [1, T): 7 loads -- dy from y_ext's
+    // address when the layer has no dy, then dropped; LD = 2: ps == T, the running gradient only).  A load under a branch leaves
+    // the compiler with paths of different pending counts: it then guards every later register write with a wait counted for the
+    // shortest path, which on the long one waits for the stores issued in between (section 4.5.6 of DESIGN.md).
+    auto epi_load_t = [&](auto LD, int ps, int r, EpiIn& in) -> int {
+        constexpr int ld = decltype(LD)::value;
+        const int s = T - 1 - ps;
+        const int t = (dir == 0) ? s : T - 1 - s;
+        const int slot_prev = (dir == 0) ? t : t + 2;
+        const int b = m_base + 32 * r + gtr;
+        const int bc = b < B ? b : B - 1;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)(((((long long)dir * p.CS + cm.member) * B + bc) * 32 + (juc & 31)) * 4), 0, AUX_SC1);
+        if constexpr (ld == 1) {
+            const float* hpp = p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc;
+            const f32x4 dyv = *reinterpret_cast<const f32x4*>(has_dy ? p.dy + ((long long)t * B + bc) * ldy + dir * H + juc : hpp);
+            const int gs = p.saved_mm ? 32 : H;
+            const float* sv = p.saved_mm ? p.saved + ((((long long)dir * T + t) * p.CS + cm.member) * B + bc) * 128 + (juc & 31)
+                                         : p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+            in.rg = *reinterpret_cast<const f32x4*>(sv);
+            in.zg = *reinterpret_cast<const f32x4*>(sv + gs);
+            in.ng = *reinterpret_cast<const f32x4*>(sv + 2 * gs);
+            in.q = *reinterpret_cast<const f32x4*>(sv + 3 * gs);
+            in.hp = *reinterpret_cast<const f32x4*>(hpp);
+            in.dy = has_dy ? dyv : z4;
+            return 7;
+        } else {
+            in.dy = z4; in.rg = z4; in.zg = z4; in.ng = z4; in.q = z4; in.hp = z4;
+            return 1;
+        }
+    };
     // gate gradients of processing step ps for (round r, this lane's trial and units); acc = dgh_{ps-1} W_hh (own units).
     // Stores: the exchange rows first (group B), then the outputs (group C, always issued: dead lanes are dropped by the range
     // check); returns the number of group-C stores.
-    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) -> int {
+    // KIND (compile time; 0: decided at run time): 1 = exchange rows + outputs (a step that is contracted further), 3 = outputs only
+    // (the last step when no dh0 is wanted), 2 = the dh0 row (ps == T)
+    auto epilogue_t = [&](auto KIND, int ps, int r, const EpiIn& in, const f32x4& acc) -> int {
+        constexpr int kind = decltype(KIND)::value;
         const int s = T - 1 - ps;
         const int t = (dir == 0) ? s : T - 1 - s;
         const int b = m_base + 32 * r + gtr;
         const bool live = b < B && ulive;
         f32x4 carry = __builtin_bit_cast(f32x4, in.keep);             // (whole vector: a bit_cast of ONE element reads element 0)
-        if (ps > 0) carry += acc;
-        if (ps == T) {
+        if (kind != 0 || ps > 0) carry += acc;
+        if (kind == 2 || (kind == 0 && ps == T)) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, carry), hr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
             return 1;
         }
@@ -795,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             danr[i] = live ? da * r_ : 0.f;
             keep[i] = dh * z_;
         }
-        if (ps + 1 < p.ps_total) {                      // someone will contract these gradients
+        if (kind == 1 || (kind == 0 && ps + 1 < p.ps_total)) {      // someone will contract these gradients
             const unsigned chunk0 = (unsigned)((((ps & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r) * 3);
             const unsigned rowoff = (unsigned)gtr * (unsigned)(KP * 4);
             const f32x4* gsrc[3] = {&dar, &daz, &danr};
@@ -830,6 +864,9 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)(((((long long)dir * p.CS + cm.member) * B + b) * 32 + (ju & 31)) * 4) : CL_OOB, 0, 0);
         return 5;
+    };
+    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) -> int {
+        return epilogue_t(std::integral_constant<int, 0>{}, ps, r, in, acc);
     };
 
     int ps0 = p.ps_begin;
@@ -909,7 +946,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                             // three of this wave's four groups; gate wave 4 + wave moves the fourth (stamps: issuing 16 pieces cost a
                             // contraction wave ~1300 cycles of a 3400-cycle sub-iteration while the gate waves idled at the barrier)
                             // (two groups on gate waves 5-7 as well: 991 vs 992 us, no further gain)
-                            if (has_next && (c & 3) == 0 && tt * 2 + (c >> 2) < 3) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
+                            // (gg == 0: the gate waves are busy with the gate math and move one group; otherwise they idle and move two)
+                            if (has_next && (c & 3) == 0 && tt * 2 + (c >> 2) < (gg == 0 ? 3 : 2)) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
                             const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
                             const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
@@ -960,77 +998,120 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     __builtin_amdgcn_s_setprio(3);   // (see the forward kernel)
     EpiIn ein;
     int pend_ps = -1, pend_r = 0;    // round whose contraction is complete and whose gate math is due
-    auto finish = [&](int qlast) -> int {   // qlast: the g == 2 sub-iteration of the pending round; returns the group-C stores
+    auto finish = [&](auto KIND, int qlast) -> int {   // qlast: the g == 2 sub-iteration of the pending round; returns the group-C stores
         // products of contraction wave (ut, kh), trial tile te: 1 KiB, lane (n, kq) of the MFMA layout at (16 kq + n) x 16 B
         const int ut_ = guq >> 2, te_ = gtr >> 4;
         const unsigned char* xa = xacc + (((qlast / 3) & 1) * 4) * 2 * 1024 + (((guq & 3) * 16 + (gtr & 15)) * 16);
         f32x4 a = *reinterpret_cast<const f32x4*>(xa + ((2 * ut_) * 2 + te_) * 1024);
         a += *reinterpret_cast<const f32x4*>(xa + ((2 * ut_ + 1) * 2 + te_) * 1024);
-        return epilogue(pend_ps, pend_r, ein, a);
+        return epilogue_t(KIND, pend_ps, pend_r, ein, a);
+    };
+#ifdef XPS_CL_STAMP
+    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0;
+    CL_STAMP(sb2)
+#endif
+    // One round = three sub-iterations (one barrier each), written out straight-line and instantiated per case -- FIN: the gate
+    // math due at g == 0 (0: none, the launch's first round; 1 / 3 / 2: see epilogue_t),
+    // LD: the inputs requested at g == 0 (see epi_load_t) -- so that no load and no store of the steady state sits under a branch.
+    //   g == 0: [DMA] gate math of the round that finished at the last barrier (exchange rows, outputs), this round's inputs,
+    //           counted wait (exchange rows + pieces complete)          g == 1: [DMA] flag, look-ahead poll          g == 2: [DMA]
+    auto round_body = [&](auto FIN, auto LD, int ps, int r) {
+        constexpr int fin = decltype(FIN)::value;
+        const int q0 = ps * NQ + 3 * r;
+        int r_n = r + 1, ps_n = ps;                           // the next round
+        if (r_n == NR) { r_n = 0; ++ps_n; }
+        const bool has_next = q0 + 3 < q_end;
+        // ---------------- g == 0 ----------------
+        if constexpr (BF) {
+            // this wave's share of the next sub-iteration's operand: the fourth group of contraction wave (wave - 4)'s quarter,
+            // first in the stream so that the counted wait covers it
+            dma_group(dma_src(ps, r, 1), (q0 + 1) & 1, 3);
+            CL_FENCE();
+        }
+        int younger = 0;                                       // operations issued after the exchange stores (see cl_wait_vmcnt)
+        if constexpr (fin != 0) younger += finish(FIN, q0 - 1);
+        CL_FENCE();
+        younger += epi_load_t(LD, ps, r, ein);                 // this round's inputs, used one round later
+        CL_FENCE();
+        CL_STAMP(sb3)
+        cl_wait_vmcnt(younger);                                // exchange rows complete; outputs / inputs stay in flight
+        CL_STAMP(sb4)
+        CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb4)
+        CL_STAMP(sb0)
+        __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1)
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
+        // ---------------- g == 1 ----------------
+        if constexpr (BF) {
+            dma_group(dma_src(ps, r, 2), (q0 + 2) & 1, 2);
+            dma_group(dma_src(ps, r, 2), (q0 + 2) & 1, 3);
+            CL_FENCE();
+        }
+        // flag of the round whose gate math ran above: its exchange rows were complete before the last barrier
+        if constexpr (fin != 0) {
+            if (p.handoff && wave == 4 && lane == 0)
+                __hip_atomic_store(myflags + pend_r * 16 + cm.member, (unsigned)(pend_ps + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // flags of the next round (its first operand image is requested during g == 2)
+        const bool do_poll = p.handoff && wave == 4 && has_next;
+        unsigned fl = 0xffffffffu;
+        if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r_n * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CL_STAMP(sb3)
+        if (do_poll) cl_wait(myflags + r_n * 16, (unsigned)ps_n, p.CS, lane, fl, p.status, p.sticky);
+        if constexpr (BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
+        CL_STAMP(sb0)
+        __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1) CL_ACC(s_poll, sb3, sb0) CL_ACC(s_work, sb2, sb3)
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
+        // ---------------- g == 2 ----------------
+        if constexpr (BF) {
+            if (has_next) { dma_group(dma_src(ps_n, r_n, 0), (q0 + 3) & 1, 2); dma_group(dma_src(ps_n, r_n, 0), (q0 + 3) & 1, 3); }
+            CL_FENCE();
+        }
+        pend_ps = ps; pend_r = r;
+        CL_STAMP(sb3)
+        if constexpr (BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CL_STAMP(sb0)
+        __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1) CL_ACC(s_poll, sb3, sb0) CL_ACC(s_work, sb2, sb3)
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
     };
     {
-        int ps = ps0, r = 0, g = 0;
-#ifdef XPS_CL_STAMP
-        unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0;
-        CL_STAMP(sb2)
-#endif
-        for (int q = q_begin; q < q_end; ++q) {
-            // flag of the round that ended at q - 2: its exchange rows were stored during sub-iteration q - 1 and complete before
-            // the last barrier
-            if constexpr (BF) {
-                // this wave's share of sub-iteration q + 1's operand: the fourth group of contraction wave (wave - 4)'s quarter,
-                // first in the stream so that the counted wait of g == 0 covers it
-                if (q + 1 < q_end) {
-                    int ps_n = ps, r_n = r, g_n = g + 1;
-                    if (g_n == 3) { g_n = 0; if (++r_n == NR) { r_n = 0; ++ps_n; } }
-                    dma_group(dma_src(ps_n, r_n, g_n), (q + 1) & 1, 3);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        bool first = true;
+        for (int ps = ps0; ps < p.ps_end; ++ps) {
+            for (int r = 0; r < NR; ++r) {
+                const int pps = r == 0 ? ps - 1 : ps;              // step of the round whose gate math is due
+                const int fk = first ? 0 : (pps == T ? 2 : (pps + 1 < p.ps_total ? 1 : 3));
+                if (ps < T) {
+                    if (fk == 1) round_body(I1{}, I1{}, ps, r);
+                    else if (fk == 3) round_body(I3{}, I1{}, ps, r);
+                    else round_body(I0{}, I1{}, ps, r);
+                } else {
+                    if (fk == 2) round_body(I2{}, I2{}, ps, r);
+                    else if (fk == 1) round_body(I1{}, I2{}, ps, r);
+                    else round_body(I0{}, I2{}, ps, r);
                 }
-                CL_FENCE();
+                first = false;
             }
-            if (p.handoff && wave == 4 && lane == 0 && g == 1 && q - 2 >= q_begin) {
-                int rp = r - 1, psp = ps;
-                if (rp < 0) { rp = NR - 1; --psp; }
-                __hip_atomic_store(myflags + rp * 16 + cm.member, (unsigned)(psp + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // flags of the round whose first sub-iteration is q + 2 (only when g == 1: q + 2 = (next round, 0))
-            int r2 = r + 1, ps2 = ps;
-            if (r2 == NR) { r2 = 0; ++ps2; }
-            const bool do_poll = p.handoff && wave == 4 && g == 1 && q + 2 < q_end;
-            unsigned fl = 0xffffffffu;
-            if (do_poll && lane < p.CS) fl = __hip_atomic_load(myflags + r2 * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g == 0) {
-                CL_FENCE();
-                int younger = 0;                               // operations issued after the exchange stores (see cl_wait_vmcnt)
-                if (pend_ps >= 0) { younger += finish(q - 1); pend_ps = -1; }
-                CL_FENCE();
-                younger += epi_load(ps, r, ein);               // this round's inputs, used one round later
-                CL_FENCE();
-                CL_STAMP(sb3)
-                cl_wait_vmcnt(younger);                        // exchange rows complete; outputs / inputs stay in flight
-                CL_STAMP(sb4)
-                CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb3, sb4)
-#ifdef XPS_CL_STAMP
-                sb2 = sb4;
-#endif
-            }
-            if (g == 2) { pend_ps = ps; pend_r = r; }
-            CL_STAMP(sb3)
-            if (do_poll) cl_wait(myflags + r2 * 16, (unsigned)ps2, p.CS, lane, fl, p.status, p.sticky);
-            if (BF && g != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed
-            CL_STAMP(sb0)
-            __syncthreads();
-            CL_STAMP(sb1)
-            CL_ACC(s_bar, sb0, sb1) CL_ACC(s_poll, sb3, sb0) CL_ACC(s_work, sb2, sb3)
-#ifdef XPS_CL_STAMP
-            sb2 = sb1;
-#endif
-            if (++g == 3) { g = 0; if (++r == NR) { r = 0; ++ps; } }
         }
 #ifdef XPS_CL_STAMP
         if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; }
 #endif
     }
-    if (pend_ps >= 0) finish(q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
+    if (pend_ps >= 0) finish(std::integral_constant<int, 0>{}, q_end - 1);                          // (outputs of the launch's last round; nobody waits for its flag)
 }
 
 // ------------------------------------------------------------------------------------------------------
