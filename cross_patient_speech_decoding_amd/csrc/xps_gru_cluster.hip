@@ -1449,16 +1449,48 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
         }
         return nload;
     };
+    // the same for an interior iteration (1 <= ps < T) without a branch around any load: 7 loads (see the 1-D kernel's epi_load_t)
+    auto epi_load_fast = [&](int ps, int r, EpiIn& in) {
+        const int s_ = T - 1 - ps;
+        const int t = (dir == 0) ? s_ : T - 1 - s_;
+        const int slot_prev = (dir == 0) ? t : t + 2;
+        const int b = m_base + C2_RT * r + gtr;
+        const int bc = b < B ? b : B - 1;
+        in.keep = __builtin_amdgcn_raw_buffer_load_b128(kr, (unsigned)(((((long long)dir * 16 + cm.member) * B + bc) * 32 + (juc & 31)) * 4), 0, AUX_SC1);
+        const float* hpp = p.y_ext + ((long long)slot_prev * B + bc) * ldy + dir * H + juc;
+        const f32x4 dyv = CL2_STREAM_LOAD(has_dy ? p.dy + ((long long)t * B + bc) * ldy + dir * H + juc : hpp);
+        const int gs = p.saved_mm ? 32 : H;
+        const float* sv = p.saved_mm ? p.saved + ((((long long)dir * T + t) * ((H + 31) / 32) + cm.member) * B + bc) * 128 + (juc & 31)
+                                     : p.saved + (((long long)dir * T + t) * B + bc) * 4 * H + juc;
+        in.rg = CL2_STREAM_LOAD(sv);
+        in.zg = CL2_STREAM_LOAD(sv + gs);
+        in.ng = CL2_STREAM_LOAD(sv + 2 * gs);
+        in.q = CL2_STREAM_LOAD(sv + 3 * gs);
+        in.hp = CL2_STREAM_LOAD(hpp);
+        in.dy = has_dy ? dyv : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     // gate gradients of processing step ps, round r for this lane's trial and four units; acc = dgh_{ps-1} W_hh (own units).
     // Stores: the exchange rows first, then the outputs (always issued: dead lanes are dropped by the range check).
-    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) {
+    // KIND 1 (compile time): an interior step -- exchange rows + outputs, no branch; 0: decided at run time.
+    struct EpiOut { f32x4 dar, daz, dan, danr, keep; unsigned go, no, ko; };
+    auto output_rows = [&](const EpiOut& o) {              // five stores (dead lanes: out of range, dropped)
+        const bool live = o.go != CL_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.dar), gr, o.go, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.daz), gr, live ? o.go + (unsigned)H * 4u : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.dan), gr, live ? o.go + (unsigned)H * 8u : CL_OOB, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.danr), nr, o.no, 0, CL2_AUX_STREAM);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.keep), kr, o.ko, 0, 0);
+    };
+    // (defer != nullptr: the output rows are not stored but handed back, for output_rows() a slot later)
+    auto epilogue_t = [&](auto KIND, int ps, int r, const EpiIn& in, const f32x4& acc, EpiOut* defer = nullptr) {
+        constexpr int kind = decltype(KIND)::value;
         const int s_ = T - 1 - ps;
         const int t = (dir == 0) ? s_ : T - 1 - s_;
         const int b = m_base + C2_RT * r + gtr;
         const bool live = b < B && ulive;
         f32x4 carry = __builtin_bit_cast(f32x4, in.keep);
-        if (ps > 0) carry += acc;
-        if (ps == T) {
+        if (kind != 0 || ps > 0) carry += acc;
+        if (kind == 0 && ps == T) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, carry), hr, live ? (unsigned)((((long long)dir * B + b) * H + ju) * 4) : CL_OOB, 0, 0);
             return;
         }
@@ -1476,7 +1508,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
             danr[i] = live ? da * r_ : 0.f;
             keep[i] = dh * z_;
         }
-        if (ps + 1 < p.ps_total) {                      // someone will contract these gradients: slice jg of round r
+        if (kind == 1 || ps + 1 < p.ps_total) {         // someone will contract these gradients: slice jg of round r
             // row of trial n, plane-row byte L = 2 (128 g + uo) -> 16-byte chunk (L >> 4) ^ n of its 256-byte window (the operand
             // image's bank swizzle, see the kernel header), byte L & 15 inside the chunk
             const unsigned base = x_chunk(ps, r, jg) + (unsigned)gtr * 1536u;
@@ -1498,14 +1530,16 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
             }
         }
         CL_FENCE();
-        const unsigned go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
         if (p.split_out) { dar = split4_pack(dar); daz = split4_pack(daz); dan = split4_pack(dan); danr = split4_pack(danr); }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dar), gr, go, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, daz), gr, live ? go + (unsigned)H * 4u : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dan), gr, live ? go + (unsigned)H * 8u : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, danr), nr, live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB, 0, CL2_AUX_STREAM);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)(((((long long)dir * 16 + cm.member) * B + b) * 32 + (ju & 31)) * 4) : CL_OOB, 0, 0);
+        EpiOut o;
+        o.dar = dar; o.daz = daz; o.dan = dan; o.danr = danr; o.keep = keep;
+        o.go = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
+        o.no = live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB;
+        o.ko = live ? (unsigned)(((((long long)dir * 16 + cm.member) * B + b) * 32 + (ju & 31)) * 4) : CL_OOB;
+        if (defer) *defer = o;
+        else output_rows(o);
     };
+    auto epilogue = [&](int ps, int r, const EpiIn& in, const f32x4& acc) { epilogue_t(std::integral_constant<int, 0>{}, ps, r, in, acc); };
 
     if (p.do_ps0) {
         // first processing step: no contraction, the running gradient starts from dhn (or zero); pair P takes the rounds r % 2 == P
@@ -1536,16 +1570,37 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
     //   s % 2 == P ("request slot"): flag of its exchange rows of iteration s - 4, quarter flags and quarters of iteration s - 2
     // (iteration i: requests in slot i + 1 and i + 2, math in slot i + 3, flag in slot i + 4: two slots per memory round trip)
     EpiIn ein;
-    f32x4 pq[4];
+    f32x4 pq[4], pown;                                     // quarters from the other members (pq[kg]: nothing) / the own one (LDS)
 #pragma unroll
     for (int c = 0; c < 4; ++c) pq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    pown = pq[0];
     int after_rows = 0;                                    // operations issued behind the exchange rows of the last math slot
 #ifdef XPS_CL_STAMP
-    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0, s_math = 0, s_q = 0;
-    unsigned long long sp1 = 0, sp2 = 0, s_m1 = 0, s_m2 = 0, s_m3 = 0, s_r1 = 0, s_r2 = 0, s_r3 = 0;
+    unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, sb4 = 0, s_bar = 0, s_work = 0, s_drain = 0, s_poll = 0;
     CL_STAMP(sb2)
 #endif
-    for (int s = s_lo; s <= s_hi; ++s) {
+    const bool own_q = p.handoff != 0;                     // the member's own quarter comes through LDS
+    // sum of the four quarters in the fixed order 0, 1, 2, 3 (the own one from its LDS copy)
+    auto quarter_sum = [&]() -> f32x4 {
+        const f32x4 q0 = (own_q && kg == 0) ? pown : pq[0], q1 = (own_q && kg == 1) ? pown : pq[1];
+        const f32x4 q2 = (own_q && kg == 2) ? pown : pq[2], q3 = (own_q && kg == 3) ? pown : pq[3];
+        return ((q0 + q1) + q2) + q3;
+    };
+    // requests for the quarters of iteration i: four loads without a branch (the own column's is sent out of range and dropped:
+    // a load under a run-time branch got a vmcnt(0) apiece from the compiler), the own quarter from LDS
+    auto quarter_requests = [&](int i) {
+        const int ps = i / NR + 1, r = i % NR;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            pq[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (own_q && c == kg) ? CL_OOB : p_off(ps, r, cm.member, c) + qtile, 0, AUX_SC1));
+        pown = *reinterpret_cast<const f32x4*>(ownq + (i & 3) * 2048 + qtile);
+    };
+    // ---- one slot, general form (edges of the launch, the last step, the one-step-per-launch modes) ----
+    // A round of 16 trials is the work of ONE pair; the other pair takes the next.  Wave of pair P, slot s:
+    //   s % 2 != P ("math slot", i = s - 3 has i % 2 == P): gate math of iteration s - 3, then the HBM requests of iteration s - 1
+    //   s % 2 == P ("request slot"): flag of its exchange rows of iteration s - 4, quarter flags and quarters of iteration s - 2
+    // (iteration i: requests in slot i + 1 and i + 2, math in slot i + 3, flag in slot i + 4: two slots per memory round trip)
+    auto slot_general = [&](int s) {
         unsigned la_img = 0xffffffffu;
         if (p.handoff && wave == 4 && valid_c(s + 3)) la_img = peek(flag_image(s + 3), false);
         CL_FENCE();
@@ -1554,23 +1609,13 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
             int younger = 0;
             if (valid_g(s - 3)) {
                 const int i = s - 3, ps = i / NR + 1;
-                const f32x4 a = ((pq[0] + pq[1]) + pq[2]) + pq[3];
-#ifdef XPS_CL_STAMP
-                asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(ein.rg[0]), "v"(ein.q[0]), "v"(ein.hp[0]), "v"(ein.dy[0]), "v"(ein.keep[0]));
-                CL_STAMP(sp1)
-#endif
-                epilogue(ps, i % NR, ein, a);
+                epilogue(ps, i % NR, ein, quarter_sum());
                 younger += ps == T ? 1 : 5;
             }
-#ifdef XPS_CL_STAMP
-            else { sp1 = sb2; }
-#endif
             CL_FENCE();
-            CL_STAMP(sp2)
             if (valid_g(s - 1)) younger += epi_load((s - 1) / NR + 1, (s - 1) % NR, ein);
             after_rows = younger;
             CL_STAMP(sb3)
-            CL_ACC(s_math, sb2, sb3) CL_ACC(s_m1, sb2, sp1) CL_ACC(s_m2, sp1, sp2) CL_ACC(s_m3, sp2, sb3)
         } else {
             // ---- request slot ----
             if (p.handoff && valid_g(s - 4)) {
@@ -1585,23 +1630,12 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
                 }
             }
             CL_FENCE();
-            CL_STAMP(sp1)
-#ifdef XPS_CL_STAMP
-            sp2 = sp1;
-#endif
             if (valid_g(s - 2)) {
-                const int i = s - 2, ps = i / NR + 1, r = i % NR;
-                if (p.handoff) wait_flags(flag_quarters(i), true, (unsigned)ps, peek(flag_quarters(i), true), 6);
-                CL_STAMP(sp2)
-                const unsigned tile = qtile;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (p.handoff && c == kg) pq[c] = *reinterpret_cast<const f32x4*>(ownq + (i & 3) * 2048 + tile);
-                    else pq[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, p_off(ps, r, cm.member, c) + tile, 0, AUX_SC1));
-                }
+                const int i = s - 2;
+                if (p.handoff) wait_flags(flag_quarters(i), true, (unsigned)(i / NR + 1), peek(flag_quarters(i), true), 6);
+                quarter_requests(i);
             }
             CL_STAMP(sb3)
-            CL_ACC(s_q, sb2, sb3) CL_ACC(s_r1, sb2, sp1) CL_ACC(s_r2, sp1, sp2) CL_ACC(s_r3, sp2, sb3)
         }
         CL_FENCE();
         CL_STAMP(sb4)
@@ -1614,10 +1648,76 @@ __global__ __launch_bounds__(512, 2) void gru_cluster2_bwd_kernel(ClBwd2 p) {
 #ifdef XPS_CL_STAMP
         sb2 = sb1;
 #endif
+    };
+    // ---- a math slot s and the request slot s + 1 of this pair, interior of the persistent launch: straight-line ----
+    // Every iteration touched (s - 3 .. s + 4) exists and lies before the last processing step, the cluster sits on one XCD.  No
+    // load sits under a branch (the compiler guards register writes behind a branch join with waits counted for the shorter path:
+    // behind eleven fresh stores they wait for the stores; the general form above loses ~1100 cycles per slot to them), every
+    // wave looks the image flags up (only wave 4 acts on them), and the quarter flags of the request slot are looked up a slot
+    // early, behind the stores of the math slot.
+    auto slots_fast = [&](int s) {
+        // ---- math slot s: gate math of iteration s - 3, requests of iteration s - 1 ----
+        unsigned la_img = peek(flag_image(s + 3), false);
+        CL_FENCE();
+        {
+            const int i = s - 3;
+            epilogue_t(std::integral_constant<int, 1>{}, i / NR + 1, i % NR, ein, quarter_sum());
+        }
+        CL_FENCE();
+        const unsigned lq = peek(flag_quarters(s - 1), true);     // consumed in the request slot
+        CL_FENCE();
+        epi_load_fast((s - 1) / NR + 1, (s - 1) % NR, ein);
+        CL_FENCE();
+        CL_STAMP(sb3)
+        CL_STAMP(sb4)
+        if (wave == 4) wait_flags(flag_image(s + 3), false, (unsigned)((s + 3) / NR + 1), la_img, 1);
+        CL_STAMP(sb0)
+        __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_drain, sb2, sb3)      /* (stamped build: s_drain = math slots, s_poll = request slots) */
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
+        // ---- request slot s + 1: flag of the exchange rows of iteration s - 3, quarters of iteration s - 1 ----
+        la_img = peek(flag_image(s + 4), false);
+        CL_FENCE();
+        cl_wait_vmcnt(5 + 1 + 7 + 1);                           // behind the exchange rows: 5 outputs, the quarter-flag look-up, 7 inputs, the image look-up
+        if (lane == 0) {
+            const int i = s - 3;
+            unsigned* f = myflags + (i % NR) * 160 + cm.member * 4 + hut;
+            __hip_atomic_store(f, (unsigned)(i / NR + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(f + 2, (unsigned)(i / NR + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        CL_FENCE();
+        // (the output rows of the math slot stored here instead, to halve that slot's vector-memory work: 789 -> 1937 us -- the
+        //  quarter requests then queue behind five HBM stores and every next math slot waits for them)
+        wait_flags(flag_quarters(s - 1), true, (unsigned)((s - 1) / NR + 1), lq, 6);
+        quarter_requests(s - 1);
+        CL_FENCE();
+        CL_STAMP(sb3)
+        CL_STAMP(sb4)
+        if (wave == 4) wait_flags(flag_image(s + 4), false, (unsigned)((s + 4) / NR + 1), la_img, 1);
+        CL_STAMP(sb0)
+        __syncthreads();
+        CL_STAMP(sb1)
+        CL_ACC(s_bar, sb0, sb1) CL_ACC(s_work, sb2, sb3) CL_ACC(s_poll, sb2, sb3)
+#ifdef XPS_CL_STAMP
+        sb2 = sb1;
+#endif
+    };
+    {
+        // interior: persistent launch over every iteration, same-XCD cluster; the slots s .. s + 1 touch iterations s - 3 .. s + 4,
+        // all of them before the last processing step (which has no exchange rows or is the dh0 step)
+        const int n_it = p.c_end;
+        const bool can_fast = p.handoff && fast && has_c && has_g && p.c_begin == 0 && p.g_begin == 0 && p.g_end == n_it;
+        int s = s_lo;
+        while (s <= s_hi) {
+            if (can_fast && ((s - pair) & 1) != 0 && s - 3 >= 0 && s + 4 < n_it - NR) { slots_fast(s); s += 2; }
+            else { slot_general(s); ++s; }
+        }
     }
 #ifdef XPS_CL_STAMP
-    if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; g_clstamp[wid * 8 + 4] = s_math; g_clstamp[wid * 8 + 5] = s_q;
-                      g_clstamp2[wid * 8 + 0] = s_m1; g_clstamp2[wid * 8 + 1] = s_m2; g_clstamp2[wid * 8 + 2] = s_m3; g_clstamp2[wid * 8 + 3] = s_r1; g_clstamp2[wid * 8 + 4] = s_r2; g_clstamp2[wid * 8 + 5] = s_r3; }
+    if (lane == 0) { const int wid = (blockIdx.x * 8 + wave) & 2047; g_clstamp[wid * 8 + 0] = s_work; g_clstamp[wid * 8 + 1] = s_drain; g_clstamp[wid * 8 + 2] = s_bar; g_clstamp[wid * 8 + 3] = s_poll; }
 #endif
 }
 
