@@ -136,6 +136,36 @@ def _run_layer(xf, x, ws, wt, ndir):
     return [y.detach().clone(), hn.detach().clone(), xg.grad.clone()] + [w.grad.clone() for w in wl]
 
 
+@pytest.mark.parametrize('need_dh0', [False, True])
+@pytest.mark.parametrize('T,B,H', [(6, 640, 512), (2, 512, 512), (5, 300, 448)])
+def test_bptt_without_dy_equals_explicit_zero_dy(T, B, H, need_dh0, gemm_precision, cluster_mode, bptt_grid):
+    """The top encoder layer of the seq2seq model gets NO dy (only the gradient of its last hidden state,
+    nn_models/models.py:690-699): the BPTT kernels then read their inputs without a branch around any load (the dy load is
+    redirected and dropped).  dy = None must give the bits of dy = 0, in the persistent form (interior fast paths of both
+    grids, edges, the last step with and without the dh0 pass) and with one launch per step."""
+    xf = XF()
+    ndir = 2
+    g = torch.Generator().manual_seed(T * 1000 + B + H)
+    gi = (0.5 * torch.randn(ndir, T, B, 3 * H, generator=g)).cuda()
+    ws = [(torch.randn(3 * H, H, generator=g) / H ** 0.5).cuda() for _ in range(ndir)]
+    bs = [(0.1 * torch.randn(3 * H, generator=g)).cuda() for _ in range(ndir)]
+    dhn = torch.randn(ndir, B, H, generator=g).cuda()
+    outs = {}
+    for mode in ('steps', 'persistent'):
+        cluster_mode(mode)
+        y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
+        for name, dy in (('none', None), ('zero', torch.zeros(T, B, ndir * H, device='cuda'))):
+            dgi, dghn, dh0 = xf._gru_backward(dy, dhn, y_ext, saved, ws, T, B, H, ndir, need_dh0)
+            torch.cuda.synchronize()
+            xf.check_gru_status()
+            outs[(mode, name)] = [dgi.clone(), dghn.clone()] + ([dh0.clone()] if need_dh0 else [])
+    ref = outs[('steps', 'zero')]
+    assert all(torch.isfinite(r).all() for r in ref) and float(ref[0].abs().max()) > 0
+    for key, val in outs.items():
+        for a, b, name in zip(val, ref, ['dgi', 'dghn', 'dh0']):
+            assert torch.equal(a, b), f'{name} of {key} differs from steps / zero dy'
+
+
 @pytest.mark.parametrize('H', [512, 500])
 def test_persistent_equals_one_launch_per_step_bitwise_full_size(H, gemm_precision, cluster_mode, bptt_grid):
     """Bench-size layer (2048 trials x 20 steps, bidirectional: the per-GPU shard of configs[3]): the in-kernel
