@@ -9,6 +9,9 @@ gi = (torch.randn(ndir, T, B, 3 * H) * 0.5).cuda()
 ws = [(torch.randn(3 * H, H) / H ** 0.5).cuda() for _ in range(ndir)]
 bs = [(torch.randn(3 * H) * 0.1).cuda() for _ in range(ndir)]
 dy = (torch.randn(T, B, ndir * H) * 0.1).cuda()
+if os.environ.get('GRID'):          # 1: the 4 x 4 BPTT grid
+    from cross_patient_speech_decoding_amd import _lib
+    _lib.lib().xps_set_gru_bptt_grid(int(os.environ['GRID']))
 for _ in range(5):
     y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
     if os.environ.get('BWD'):
