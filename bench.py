@@ -304,7 +304,10 @@ def roofline_cluster(model, c, dev):
                     {'kernel': 'gemm_big_tn_kernel + reduce (dW_ih of encoder layer 1: 1536 x 1024 x 40960, 256 x 256 tiles)', 'bound': 'mfma',
                      'achieved': round(issued * fl_g / t_g / 1e12, 1), 'peak': peak, 'unit': 'TFLOP/s (issued MFMA work)',
                      'frac': round(issued * fl_g / t_g / 1e12 / peak, 4), 'launch_us': round(t_g * 1e6, 1), 'flops_per_launch': fl_g,
-                     'algorithmic_tflops': round(fl_g / t_g / 1e12, 1)}]}
+                     'algorithmic_tflops': round(fl_g / t_g / 1e12, 1),
+                     # context, not the denominator: a pure MFMA loop on random bf16 operands reaches 0.70 of `peak` on this
+                     # chip (clock 2.33 -> 1.67 GHz under toggling inputs): profiles/round3/mfma_clock.txt
+                     'mfma_rate_on_random_operands_tflops': 1760.0}]}
     return out
 
 
