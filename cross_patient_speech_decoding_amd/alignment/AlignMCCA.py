@@ -50,10 +50,11 @@ class DeviceMCCA:
         Z = LA.torch.cat(Vd, dim=1).contiguous()
         mean = LA.torch.cat([LA.col_mean(v) for v in Vd])
         # centred Gram of the concatenated views, one block row per view (f64 MFMA); sharded: own rows only, then exchanged
-        rows = [LA.xcov(Vd[i], Z, mean[offs[i]:offs[i + 1]].contiguous(), mean) if i % world == rank else None for i in range(P)]
+        rows = self.own_block_rows(Vd, Z, mean, offs, world, rank)
         if world > 1:
             rows = [_bcast_matrix(rows[i], i % world, group) for i in range(P)]
         G = LA.torch.cat(rows, dim=0).cpu().numpy()           # (D, D)
+        self.gram_ = G                                        # centred Gram of the concatenated views (before any rank reduction)
         self.block_rows_computed_ = [i for i in range(P) if i % world == rank]
         self.means_ = [mean[offs[i]:offs[i + 1]].cpu().numpy() for i in range(len(Vd))]
         self._means_d = [mean[offs[i]:offs[i + 1]].contiguous() for i in range(len(Vd))]
@@ -82,6 +83,14 @@ class DeviceMCCA:
         self._load_d = [LA.to_device(np.ascontiguousarray(l)) for l in self.loadings_]
         self.n_views_ = len(Vd)
         return self
+
+    @staticmethod
+    def own_block_rows(Vd, Z, mean, offs, world, rank):
+        """Block rows C_{p,.} = (L_p - mean_p)^T [L_1 - mean_1 ... L_P - mean_P] of the views rank `rank` of `world` owns
+        (p % world == rank; None for the others): one xps_xcov_f64 launch group per view -- the SAME launches whatever the
+        world size, which is what makes the sharded fit bit-identical to the single-process one."""
+        return [LA.xcov(Vd[i], Z, mean[offs[i]:offs[i + 1]].contiguous(), mean) if i % world == rank else None
+                for i in range(len(Vd))]
 
     def transform_view(self, X, view):
         return LA.like_input(LA.apply(LA.to_device(X), self._load_d[view], self._means_d[view]), X)

@@ -18,13 +18,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
-ARGS = (10, 12, 16, 9, 2, 1, 5, 5, 0, 0.0, 0.0)
+# --shape: the model / batch the data-parallel step is checked on.  'tiny' is the host-logic case (unequal shards); the
+# other two are BASELINE shapes (SURVEY 8e's invariant "N-rank gradients == 1-rank gradients" on the kernels bench.py runs):
+#   h128 = configs[1] (C = 64, F = 100, k = s = 10, H = 128: resident GRU kernels, grouped weight-gradient launch),
+#   h512 = configs[3] (aligned d = 30, H = 512: cluster recurrence, wide decoder, 256-tile split-K groups), 512 trials
+SHAPES = {'tiny': ((10, 12, 16, 9, 2, 1, 5, 5, 0, 0.0, 0.0), (46, 40, 10), True),
+          'h128': ((64, 100, 128, 9, 2, 1, 10, 10, 0, 0.0, 0.0), (512, 200, 64), False),
+          'h512': ((30, 100, 512, 9, 2, 1, 10, 10, 0, 0.0, 0.0), (512, 200, 30), False)}
+SHAPE = ['tiny']
 
 
 def data():
     rng = np.random.default_rng(3)
-    X = torch.from_numpy(rng.standard_normal((46, 40, 10)).astype(np.float32))      # 46 rows: unequal shards at world 4
-    y = torch.from_numpy(rng.integers(0, 9, (46, 3)))
+    shp = SHAPES[SHAPE[0]][1]
+    X = torch.from_numpy(rng.standard_normal(shp).astype(np.float32))      # tiny: 46 rows = unequal shards at world 4
+    y = torch.from_numpy(rng.integers(0, 9, (shp[0], 3)))
     return X, y
 
 
@@ -32,7 +40,8 @@ def hip_step(rank, world, X, y, group):
     from weights import weights_from_seed
     from cross_patient_speech_decoding_amd.nn_models import Seq2SeqRNN
     from cross_patient_speech_decoding_amd.nn_models.trainer import FlatAdamW
-    m = Seq2SeqRNN(*ARGS, 'gru', 1e-3, 1e-5, activation=True)
+    args, _, act = SHAPES[SHAPE[0]]
+    m = Seq2SeqRNN(*args, 'gru', 1e-3, 1e-5, activation=act)
     m.load_state_dict(weights_from_seed(m.state_dict(), 5))
     m = m.cuda().train()
     m.temporal_conv.process_group = group
@@ -44,6 +53,8 @@ def hip_step(rank, world, X, y, group):
     loss = m.criterion(logits.view(-1, 9), ys.view(-1)) * (xs.shape[0] * world / X.shape[0])
     loss.backward()
     opt.step()
+    from cross_patient_speech_decoding_amd.nn_models import functional as XF
+    XF.check_gru_status()                     # (cluster recurrence: no hand-off gave up)
     gnorm = opt.grad_norm()
     # numpy (pickled by value): torch tensors would travel as file descriptors of a process that may be gone
     return (opt.flat_g.cpu().numpy(), opt.flat_p.cpu().numpy(), float(gnorm), m.temporal_conv.bn.running_var.cpu().numpy())
@@ -82,7 +93,8 @@ def sharded_mcca(group):
     return loads, tr, list(al.mcca.block_rows_computed_), Xp.numpy(), yp.numpy(), zt
 
 
-def worker(rank, world, device, q):
+def worker(rank, world, device, q, shape='tiny'):
+    SHAPE[0] = shape
     if device == 'nccl':
         # the production configuration: one process per GPU, RCCL (backend 'nccl'), device bound at init
         torch.cuda.set_device(rank)
@@ -142,7 +154,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--world', type=int, default=2)
     ap.add_argument('--device', default='cpu')
+    ap.add_argument('--shape', default='tiny', choices=sorted(SHAPES))
     a = ap.parse_args()
+    SHAPE[0] = a.shape
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     if a.device == 'nccl1':
@@ -175,7 +189,7 @@ def main():
         return
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, a.world, a.device, q)) for r in range(a.world)]
+    procs = [ctx.Process(target=worker, args=(r, a.world, a.device, q, a.shape)) for r in range(a.world)]
     for p in procs:
         p.start()
     res = q.get(timeout=300)

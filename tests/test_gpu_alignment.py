@@ -270,6 +270,82 @@ def test_align_mcca_vs_oracle_and_properties(pca_var):
         A().AlignMCCA().transform(feats)
 
 
+_north_star_views = {}
+
+
+def _north_star_mcca_inputs():
+    """Eight north-star patients (C = 128 channels, T = 200 samples, 64 shared conditions): 192 trials each --
+    the condition-averaged views are the full 64 x 200 = 12 800 rows x 128 channels of the north-star fit (D = 1024);
+    the trial count only sets how much noise the averages keep."""
+    if not _north_star_views:
+        from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+        pats = [make_patient(p, 192, T=200, C=128, n_cond=64) for p in range(8)]
+        _north_star_views['d'] = ([x for x, _ in pats], [y for _, y in pats])
+    return _north_star_views['d']
+
+
+@pytest.mark.parametrize('pca_var', [1, 0.8])
+def test_align_mcca_north_star_size_vs_oracle(pca_var):
+    """north_star's "per-patient cross-covariance accumulation plus generalized eigensolve for MCCA" END TO END at its own
+    size: 8 views x 128 channels, 64 shared conditions x 200 samples (12 800 x 1024), AlignMCCA(n_components=30, regs=0.5)
+    as scripts/aligned_decode_svm_ncv.py:180-185 builds it, pca_var 1 and 0.8 (signal ranks from the raw data,
+    alignment/AlignMCCA.py:146-150), against oracle/mcca_oracle.py (scipy.linalg.eigh on the 1024 x 1024 pencil): eigenvalues
+    1e-9, loadings and transforms of every view 1e-6 up to the sign of a component, generalised-eigen residual and
+    RHS-orthonormality of the device solution, and the block rows an 8-rank fit computes (one view per rank)
+    assembled to the bits of the single-process Gram matrix and to the oracle's LHS.  Reference call site:
+    alignment/AlignMCCA.py:140-154 (the third-party arithmetic itself stays parity-unpinned: DESIGN section 2)."""
+    from cross_patient_speech_decoding_amd.alignment.AlignMCCA import DeviceMCCA
+    la = LA()
+    feats, labs = _north_star_mcca_inputs()
+    k = 30
+    ref = mo.get_mcca_transforms(feats, labs, n_components=k, regs=0.5, pca_var=pca_var)
+    al = A().AlignMCCA(n_components=k, regs=0.5, pca_var=pca_var)
+    out = al.fit_transform(feats, labs)
+    assert len(al.mcca.loadings_) == 8 and al.mcca.block_rows_computed_ == list(range(8))
+    if pca_var != 1:
+        assert al.mcca.signal_ranks == ref.signal_ranks and max(ref.signal_ranks) < 30
+    np.testing.assert_allclose(al.mcca.evals_, ref.evals_, rtol=1e-9, atol=1e-10)
+    gaps = np.abs(np.diff(ref.evals_)) / np.abs(ref.evals_).max()
+    assert gaps.min() > 2e-7, gaps.min()                 # (the comparison of eigenVECTORS below presumes simple eigenvalues)
+    for i in range(8):
+        assert al.mcca.loadings_[i].shape == (128, k)
+        _match_up_to_sign(al.mcca.loadings_[i], ref.loadings_[i], 1e-6)
+        np.testing.assert_allclose(al.mcca.means_[i], ref.means_[i], rtol=1e-12, atol=1e-12)
+    # one sign per component for the whole solution (the sign rule acts on the common scores)
+    V, Vr = np.vstack(al.mcca.loadings_), np.vstack(ref.loadings_)
+    sg = np.sign((V * Vr).sum(0))
+    assert np.abs(V * sg - Vr).max() <= 1e-6 * np.abs(Vr).max()
+    for i in (0, 3, 7):
+        exp = mo.mcca_transform(ref, feats[i][:16], i) * sg
+        got = np.asarray(al.transform(feats[i][:16], idx=i))
+        assert got.shape == (16, 200, k) and out[i].shape == (192, 200, k)
+        assert np.abs(got - exp).max() <= 1e-6 * max(1.0, np.abs(exp).max())
+        np.testing.assert_array_equal(np.asarray(out[i][:16]), got)
+    # the pencil of the oracle, and the block rows of an 8-rank layout (rank r owns view r: ITS xps_xcov_f64 launches only)
+    views = [a.reshape(-1, a.shape[-1]) for a in ao.extract_group_conditions(feats, labs)]
+    assert views[0].shape == (12800, 128)
+    cent = [v - v.mean(0) for v in views]
+    Zc = np.concatenate(cent, axis=1)
+    Gref = Zc.T @ Zc
+    Vd = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in views]
+    offs = np.arange(9) * 128
+    Z = torch.cat(Vd, dim=1).contiguous()
+    mean = torch.cat([la.col_mean(v) for v in Vd])
+    rows = [None] * 8
+    for r in range(8):
+        own = DeviceMCCA.own_block_rows(Vd, Z, mean, offs, 8, r)
+        assert [j for j, b in enumerate(own) if b is not None] == [r]
+        rows[r] = own[r].cpu().numpy()
+    G8 = np.concatenate(rows, axis=0)
+    np.testing.assert_array_equal(G8, al.mcca.gram_)                         # 8-rank assembly == single-process matrix, bit for bit
+    assert np.abs(G8 - Gref).max() <= 1e-10 * np.abs(Gref).max()
+    assert np.abs(G8 - G8.T).max() <= 1e-10 * np.abs(Gref).max()
+    if pca_var == 1:
+        LHS, RHS = mo.mcca_gevp_blocks(cent, 0.5)
+        np.testing.assert_allclose(LHS @ V, RHS @ V * al.mcca.evals_, atol=1e-8 * np.abs(LHS).max())
+        np.testing.assert_allclose(V.T @ RHS @ V, np.eye(k), atol=1e-9)
+
+
 def test_n_components_var_bug_compatible():
     rng = np.random.default_rng(3)
     X = rng.standard_normal((500, 7, 6)) * np.array([5, 3, 2, 1, 0.5, 0.1])

@@ -128,6 +128,26 @@ def test_data_parallel_two_ranks_equal_single_process():
     assert 'DP_OK' in out.stdout
 
 
+@pytest.mark.parametrize('shape', ['h128', 'h512'])
+def test_data_parallel_two_ranks_equal_single_process_at_baseline_shapes(shape):
+    """SURVEY 8e's invariant -- N-rank gradients == 1-rank gradients -- ON THE KERNELS bench.py RUNS: configs[1] (C = 64,
+    H = 128: resident GRU kernels, grouped weight-gradient launch, weight-stationary projections) and configs[3] (aligned
+    d = 30, H = 512: cluster recurrence, wide decoder, 256-tile split-K groups), 512 trials over two ranks (gloo rendezvous,
+    both ranks on the box's GPU), SyncBN statistics, the two-piece overlapped all-reduce of the flat gradient: flat gradient
+    to 2e-4 of its largest element, clipped gradient norm, BatchNorm running statistics, AdamW-updated weights.  At H = 512
+    the two PROCESSES share one GPU, so the recurrence runs one step per launch (XPS_GRU_CLUSTER=steps: the same kernels,
+    bit-identical to the persistent form -- tests/test_gpu_gru_cluster.py -- without two persistent grids waiting for each
+    other's CUs; one process per GPU, the production layout, is not affected)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561' if shape == 'h128' else '29563',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if shape == 'h512':
+        env['XPS_GRU_CLUSTER'] = 'steps'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), '--world', '2', '--device', 'cuda',
+                          '--shape', shape], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert 'DP_OK' in out.stdout
+
+
 def test_rccl_collectives_execute_on_a_one_rank_communicator():
     """A one-GPU box cannot hold two RCCL ranks, but it can hold ONE: the worker replaces functional._dp_enabled (test side: the
     product rule is "more than one rank") so that the data-parallel paths run at world size 1, and `init_process_group('nccl', device_id=)`, the SyncBN exchanges, `ReduceOp.AVG` on the flat
