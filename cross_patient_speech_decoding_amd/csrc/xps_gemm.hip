@@ -22,6 +22,7 @@
 #include "xps_common.h"
 #include "xps_gemm_tile.h"
 #include "xps_gemm_big.h"
+#include "xps_gemm_dma.h"
 using namespace xps_tile;
 #ifndef XPS_GEMM_DEFAULT_MODE
 #define XPS_GEMM_DEFAULT_MODE 1
@@ -298,7 +299,8 @@ struct TnProb {
     int splits, kchunk, tiles_n, vecA, vecB;
     long long slab_off;       // float offset of this problem's slabs in the workspace
     int block_start;          // first flat block id (of the launch that serves this problem)
-    int big;                  // != 0: served by the 256 x 256 tile kernel (gemm_big_tn_kernel), same slab layout
+    int big;                  // != 0: served by the 256 x 256 tile kernel (gemm_big_tn_kernel), same slab layout; 2: both operands
+                              // are XPS_FMT_SPLIT4 and the block runs the LDS-DMA k loop (xps_gemm_dma.h)
 };
 struct TnGroup {
     TnProb p[TN_MAXP];
@@ -640,6 +642,26 @@ __global__ __launch_bounds__(512, 1) void gemm_big_tn_kernel(TnGroup g, float* _
     const bool want_cs = P.colsum && tn == 0;
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
+    if (!DEEP && P.big == 2) {
+        // both operands carry the hi / lo split: LDS-DMA k loop (no staging registers, no split arithmetic, no ds_write); the
+        // column sums ride on the matrix pipe.  Same products, bit for bit, as the register-staged loop below.
+        // column sums: the n-tile blocks of an A tile share its eight 32-column groups (block tn: groups [cs_lo, cs_hi))
+        f32x16 cacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+        const int per = (8 + tiles_n - 1) / tiles_n;
+        const int cs_lo = min(8, tn * per), cs_hi = min(8, cs_lo + per);
+        const bool cs_here = P.colsum && cs_lo < cs_hi;
+        if (cs_here) xps_big::tn_dma_pipeline<true>(acc, cacc, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, (kend - kbeg) / BKT, big_smem, cs_lo, cs_hi);
+        else xps_big::tn_dma_pipeline<false>(acc, cacc, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, (kend - kbeg) / BKT, big_smem);
+        float* subd[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            subd[s] = slab + ((long long)(2 * tm + (s >> 1)) * P.tiles_n + 2 * tn + (s & 1)) * TN_TILE;
+        xps_big::big_slab_store(acc, subd);
+        if (cs_here) xps_big::dma_colsum_store(cacc, slab + ntiles128 * TN_TILE + tm * xps_big::TM, cs_lo, cs_hi);
+        return;
+    }
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     big_accumulate<false, false, DEEP>(acc, csum, want_cs, P.A, P.ra.ld, P.B, P.rb.ld, tm * xps_big::TM, tn * xps_big::TN, kbeg, kend,
                                        !DEEP && (P.vecA & 2) != 0, !DEEP && (P.vecB & 2) != 0);
@@ -741,10 +763,13 @@ std::atomic<int>& big_switch() {
     return on;
 }
 inline bool big_enabled() { return big_switch().load(std::memory_order_relaxed) != 0 && bf_mode(); }
+// LDS-DMA k loop of the 256-tile weight-gradient kernel (xps_gemm_dma.h); XPS_GEMM_DMA=0 (read per call: A/B tests toggle it)
+inline bool dma_enabled() { const char* e = getenv("XPS_GEMM_DMA"); return !(e && e[0] == '0'); }
 // weight-stationary projection kernel (proj_ws_kernel): XPS_PROJ_WS=0 keeps the tile kernels (read per call: A/B tests toggle it)
 inline bool proj_ws_enabled() { const char* e = getenv("XPS_PROJ_WS"); return !(e && e[0] == '0'); }
 inline bool big_plain(const float* p, const RowMap& r, int rows) { return aligned16(p) && r.ld % 4 == 0 && r.rpg >= rows; }
 constexpr int BIG_LDS = (int)sizeof(xps_big::BigStage), BIG_LDS32 = (int)sizeof(xps_big::BigStage32);
+constexpr int BIG_TN_LDS = BIG_LDS > xps_big::DMA_LDS ? BIG_LDS : xps_big::DMA_LDS;      // the weight-gradient kernel holds both k loops
 template <typename Kern>
 inline bool big_prepare(Kern kern, int bytes) {
     // once per kernel: allow the 96- / 144-KB dynamic LDS block
@@ -1138,7 +1163,9 @@ int build_group(const xps_tn_problem* probs, int n, TnGroup& g, size_t& ws_float
         P.vecA = (int)map_vec_ok(q.A, P.ra) | fA;
         P.vecB = (int)map_vec_ok(q.B, P.rb) | fB;
         P.slab_off = off;
-        P.big = isbig[i] ? 1 : 0;
+        // LDS-DMA k loop: both operands XPS_FMT_SPLIT4 (the loop reads the split in place), whole 16-deep k-tiles per split
+        // (kchunk and K multiples of 16: isbig), XPS_GEMM_DMA=0: the register-staged loop
+        P.big = isbig[i] ? ((fA && fB && dma_enabled()) ? 2 : 1) : 0;
         if (isbig[i]) {
             P.block_start = blocks_big;
             blocks_big += (q.M / xps_big::TM) * (q.N / xps_big::TN) * sp;
@@ -1219,9 +1246,9 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
     bool anypre = false;                   // a 128-tile problem with an XPS_FMT_SPLIT4 operand: the kernel instantiation that reads the flags
     for (int i = 0; i < n; ++i) anypre = anypre || (!g.p[i].big && ((g.p[i].vecA | g.p[i].vecB) & 2));
     if (g.total_blocks_big > 0) {
-        static const bool ready = big_prepare(gemm_big_tn_kernel<false>, BIG_LDS) && big_prepare(gemm_big_tn_kernel<true>, BIG_LDS32);
+        static const bool ready = big_prepare(gemm_big_tn_kernel<false>, BIG_TN_LDS) && big_prepare(gemm_big_tn_kernel<true>, BIG_LDS32);
         if (!ready) {
-            xps_set_error("xps_gemm_tn_grouped_f32: cannot reserve %d bytes of LDS", BIG_LDS32);
+            xps_set_error("xps_gemm_tn_grouped_f32: cannot reserve %d bytes of LDS", BIG_LDS32 > BIG_TN_LDS ? BIG_LDS32 : BIG_TN_LDS);
             return XPS_E_HIP;
         }
         // measured: the [k][x] x [k][x] form gains nothing from 32-deep stages (its fetches are full lines already) and loses
@@ -1233,7 +1260,7 @@ extern "C" int xps_gemm_tn_grouped_f32(const xps_tn_problem* probs, int n, void*
             hipLaunchKernelGGL(gemm_big_tn_kernel<true>, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, g,
                                (float*)workspace);
         else
-            hipLaunchKernelGGL(gemm_big_tn_kernel<false>, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_LDS, (hipStream_t)stream, g,
+            hipLaunchKernelGGL(gemm_big_tn_kernel<false>, dim3(g.total_blocks_big), dim3(xps_big::NTHR), BIG_TN_LDS, (hipStream_t)stream, g,
                            (float*)workspace);
         XPS_CHECK_LAUNCH();
     }

@@ -33,6 +33,7 @@
 #include <string.h>
 #include <type_traits>
 #include "xps_common.h"
+#include <atomic>
 #include "xps_gemm_tile.h"
 using xps_tile::bf16x4;
 using xps_tile::bf16x8;
@@ -1738,7 +1739,11 @@ struct ClPlan {
 // spins across workgroups, so its whole grid must be co-resident), and the caller's sticky status word.
 struct ClDev {
     int cus = -1;
-    int resident[2][2] = {{-1, -1}, {-1, -1}};        // [fwd / bwd][fp32 / bf16x3]
+    // [kernel kind: forward / 1-D BPTT / 2-D BPTT][fp32 / bf16x3]; the (kernel, LDS bytes) pair is part of the key: the 2-D BPTT
+    // kernel has another LDS block and register count than the 1-D one.  Relaxed atomics: the autograd thread and
+    // the main thread may both ask; either computes the same value.
+    std::atomic<int> resident[3][2];
+    ClDev() { for (auto& k : resident) for (auto& v : k) v.store(-1, std::memory_order_relaxed); }
     unsigned* sticky = nullptr;
 };
 constexpr int CL_MAX_DEV = 64;
@@ -1861,17 +1866,20 @@ bool cl_set_lds(K kernel, int bytes) {
 inline bool cl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // workgroups of `kernel` (512 threads, `lds` bytes) the current device holds at once; cached per device and kernel kind
+// (kind: 0 forward, 1 one-dimensional BPTT, 2 two-dimensional BPTT -- each kind is ONE (kernel, lds) pair per precision)
 template <typename K>
-int cl_resident(K kernel, int lds, int bwd, int bf) {
+int cl_resident(K kernel, int lds, int kind, int bf) {
     const int dev = cl_device();
     if (dev < 0) return 0;
-    int& slot = g_cldev[dev].resident[bwd][bf];
-    if (slot < 0) {
+    std::atomic<int>& slot = g_cldev[dev].resident[kind][bf];
+    int v = slot.load(std::memory_order_relaxed);
+    if (v < 0) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 512, (size_t)lds) != hipSuccess) per_cu = 0;
-        slot = per_cu * cl_num_cus();
+        v = per_cu * cl_num_cus();
+        slot.store(v, std::memory_order_relaxed);
     }
-    return slot;
+    return v;
 }
 
 unsigned* cl_sticky() {
@@ -2004,7 +2012,7 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
         q.ps_total = ps_total;
         if (!cl_set_lds(gru_cluster2_bwd_kernel, C2_LDS)) { xps_set_error("gru cluster backward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
         const int n_it = (ps_total - 1) * p2.NR;
-        const bool persistent = cl_mode() == 2 && p2.grid <= cl_resident(gru_cluster2_bwd_kernel, C2_LDS, 1, 1);
+        const bool persistent = cl_mode() == 2 && p2.grid <= cl_resident(gru_cluster2_bwd_kernel, C2_LDS, 2, 1);
         if (persistent) {
             q.handoff = 1; q.do_ps0 = 1; q.c_begin = 0; q.c_end = n_it; q.g_begin = 0; q.g_end = n_it;
             hipLaunchKernelGGL(gru_cluster2_bwd_kernel, dim3(p2.grid), dim3(512), C2_LDS, st, q);

@@ -168,7 +168,10 @@ __global__ __launch_bounds__(SVM_THREADS) void svm_smo_kernel(const double* __re
 
 }  // namespace
 
-extern "C" size_t xps_svm_smo_f64_max_points(void) { return (160 * 1024 - 1024) / 28; }
+// the launch asks for max_points * 28 + 64 bytes of dynamic LDS beside ~112 bytes of static LDS (budgeted as 128) under the
+// limit of 160 KiB - 1 KiB raised below: the largest problem that LAUNCHES (5813 / 5814 passed the check and failed at launch)
+constexpr size_t SVM_LDS_LIMIT = 160 * 1024 - 1024, SVM_LDS_FIXED = 64 + 128;
+extern "C" size_t xps_svm_smo_f64_max_points(void) { return (SVM_LDS_LIMIT - SVM_LDS_FIXED) / 28; }
 
 extern "C" int xps_svm_smo_f64(const double* K, int64_t ldk, const int* idx, const int* off, const int* npos, int nprob, int max_points,
                                const double* cbound, double eps, int max_iter, double* alpha, double* rho, int* iters, void* stream) {
@@ -177,7 +180,7 @@ extern "C" int xps_svm_smo_f64(const double* K, int64_t ldk, const int* idx, con
     XPS_CHECK_ARG(max_points >= 1 && (size_t)max_points <= xps_svm_smo_f64_max_points(), "a binary problem exceeds the LDS-resident limit");
     if (nprob == 0) return XPS_OK;
     const int lds = max_points * 28 + 64;
-    static const bool ok = hipFuncSetAttribute((const void*)svm_smo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute((const void*)svm_smo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SVM_LDS_LIMIT) == hipSuccess;
     if (!ok && lds > 64 * 1024) { xps_set_error("xps_svm_smo_f64: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
     hipLaunchKernelGGL(svm_smo_kernel, dim3(nprob), dim3(SVM_THREADS), lds, (hipStream_t)stream, K, (long long)ldk, idx, off, npos, cbound, eps,
                        max_iter, alpha, rho, iters);

@@ -384,6 +384,15 @@ def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     return y_ext, saved
 
 
+def hprev_split_wanted(T, B, H, ndir):
+    """The weight-gradient group of a large layer (256 < H <= 512, bf16x3 mode: where dgi / dghn are XPS_FMT_SPLIT4 operands and the
+    256-tile kernels run) reads h_prev from an XPS_FMT_SPLIT4 image of the state sequence, made by one pass on the stream that
+    carries the group: with BOTH operands split the dW_hh products take the LDS-DMA k loop (csrc/xps_gemm_dma.h) -- the group of
+    configs[3]'s layer 1 1.07-1.2 ms -> 0.95 ms (tools/bench_wgrad_group.py) for a 0.37-GB pass.  XPS_HPREV_SPLIT=0: never."""
+    return (split4_wanted(T, B, H, ndir) and (ndir * H) % 4 == 0 and T * B >= 4096 and H % 256 == 0
+            and os.environ.get('XPS_HPREV_SPLIT', '1') != '0' and os.environ.get('XPS_GEMM_DMA', '1') != '0')
+
+
 def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=None, split4=False):
     """BPTT kernel.  dy (T,B,ndir*H) or None, dhn (ndir,B,H) or None.  Returns dgi (ndir,T,B,3H),
     dghn (ndir,T,B,H), dh0 (ndir,B,H) or None.  split4 (only where split4_supported): dgi / dghn hold XPS_FMT_SPLIT4
@@ -422,10 +431,11 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=Non
     return dgi, dghn, dh0
 
 
-def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H, ndir, fmt=0):
+def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H, ndir, fmt=0, y_fmt=0):
     """dW_hh = dgh^T h_prev and db_hh = colsum(dgh) as grouped-TN problems.  h_prev(t) are slots of
     y_ext (forward: slots 0..T-1, reverse: slots 2..T+1); the r,z rows of dgh are dgi's, the n rows dghn.
-    fmt = 1: dgi / dghn are XPS_FMT_SPLIT4 operands (_gru_backward(split4=True))."""
+    fmt = 1: dgi / dghn are XPS_FMT_SPLIT4 operands (_gru_backward(split4=True)); y_fmt = 1: so is `y_ext` (a split4 image of
+    the state sequence: hprev_split_wanted)."""
     dev = y_ext.device
     ldy = ndir * H
     probs, rets = [], []
@@ -438,9 +448,9 @@ def _recurrent_grad_problems(dgi, dghn, y_ext, w_hh_params, b_hh_params, T, B, H
             rw, rb = dw, db
         first_slot = 0 if d == 0 else 2
         hprev = y_ext.view(-1)[first_slot * B * ldy + d * H:]
-        probs.append(tn_problem(dgi[d], hprev, dw, 2 * H, H, T * B, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(ldy), rc=rowmap(H),
+        probs.append(tn_problem(dgi[d], hprev, dw, 2 * H, H, T * B, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(ldy, fmt=y_fmt), rc=rowmap(H),
                                 colsum_out=db, accumulate=acc_w))
-        probs.append(tn_problem(dghn[d], hprev, dw[2 * H:], H, H, T * B, ra=rowmap(H, fmt=fmt), rb=rowmap(ldy), rc=rowmap(H),
+        probs.append(tn_problem(dghn[d], hprev, dw[2 * H:], H, H, T * B, ra=rowmap(H, fmt=fmt), rb=rowmap(ldy, fmt=y_fmt), rc=rowmap(H),
                                 colsum_out=db[2 * H:], accumulate=acc_w))
         rets.append((rw, rb))
     return probs, rets
@@ -607,8 +617,10 @@ class GRULayerFmtFn(torch.autograd.Function):
         dev = x.device
         # weight gradients first: on the side stream they depend on the recurrence kernel only, so they start
         # together with the input-gradient GEMM below instead of after it (and are out of the way earlier)
-        probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_ext, [wb[4 * d + 1] for d in range(ndir)],
-                                                  [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir, fmt)
+        y_fmt = 1 if (fmt and hprev_split_wanted(T, B, H, ndir)) else 0
+        y_src = torch.empty_like(y_ext) if y_fmt else y_ext           # (filled on the stream that carries the group: below)
+        probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_src, [wb[4 * d + 1] for d in range(ndir)],
+                                                  [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir, fmt, y_fmt)
         rets_ih = []
         for d in range(ndir):
             dw, acc_w, rw = _grad_target(wb[4 * d + 0], (3 * H, In), dev)
@@ -621,7 +633,11 @@ class GRULayerFmtFn(torch.autograd.Function):
                                     colsum_out=db, accumulate=acc_w))
             rets_ih.append((rw, rb))
         direct = all(r[0] is None and r[1] is None for r in rets_ih + rets_hh)
-        _launch_weight_grads(lambda st: gemm_tn_grouped(probs, dev, st), dev, (dgi, dghn, x, y_ext), direct)
+        def launch_group(st):
+            if y_fmt:
+                call('xps_split4_f32', _ptr(y_ext), _ptr(y_src), y_ext.numel(), 0.0, 0, _stream() if st is None else st)
+            return gemm_tn_grouped(probs, dev, st)
+        _launch_weight_grads(launch_group, dev, (dgi, dghn, x, y_ext, y_src), direct)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, In, dtype=_f32, device=dev)

@@ -169,6 +169,51 @@ def test_weight_gradient_group_mixes_both_tile_shapes(tiles):
         assert torch.equal(b, a)                       # deterministic
 
 
+@pytest.mark.parametrize('K,M,N,ldb,boff,cs,acc', [(8192, 1536, 1024, 1024, 0, True, False),      # dW_ih of configs[3] layer 1 (short K)
+                                                   (40960, 1024, 512, 1024, 512, True, True),    # the r, z rows of a dW_hh at full K: B a column window
+                                                   (5120, 512, 256, 256, 0, False, False),       # splits with a ragged last chunk
+                                                   (4096, 256, 256, 256, 0, True, False)])
+def test_weight_gradient_lds_dma_loop_equals_register_staged_loop_bitwise(K, M, N, ldb, boff, cs, acc, tiles, monkeypatch):
+    """The LDS-DMA k loop of the 256-tile weight-gradient kernel (csrc/xps_gemm_dma.h: XPS_FMT_SPLIT4 operands read in place, no
+    staging registers / split arithmetic / ds_write) against the register-staged loop (XPS_GEMM_DMA=0) and against the
+    128-tile kernels on the SAME split4 operands: products bit for bit (same MFMA order per accumulator), against fp64 within
+    the split-product bound; the column sums (on the matrix pipe in the DMA loop: another summation order) within the split4
+    rule 2^-16 sum |a| of both the fp64 sums and the register-staged loop's; deterministic."""
+    xf = XF()
+    g = torch.Generator().manual_seed(K + M)
+    A = torch.randn(K, M, generator=g).cuda()
+    Bfull = (torch.randn(K, ldb, generator=g) * 0.5).cuda()
+    A4, B4 = xf.split4(A), xf.split4(Bfull)
+    Bv = B4.view(-1)[boff:]
+    C0 = torch.randn(M, N, generator=g).cuda()
+
+    def run():
+        out = C0.clone() if acc else torch.empty(M, N, device='cuda')
+        db = torch.zeros(M, device='cuda') if cs else None
+        keep = xf.gemm_tn_grouped([xf.tn_problem(A4, Bv, out, M, N, K, ra=rowmap(M, fmt=1), rb=rowmap(ldb, fmt=1), rc=rowmap(N),
+                                                 colsum_out=db, accumulate=acc)], 'cuda')
+        torch.cuda.synchronize()
+        del keep
+        return out, db
+
+    tiles(1)
+    monkeypatch.setenv('XPS_GEMM_DMA', '1'); dma, dma_cs = run()
+    again, again_cs = run()
+    monkeypatch.setenv('XPS_GEMM_DMA', '0'); reg, reg_cs = run()
+    tiles(0); small, small_cs = run()
+    assert torch.equal(dma, reg) and torch.equal(dma, again)
+    a64, b64 = A.double(), Bfull.double()[:, boff:boff + N]
+    ref = a64.T @ b64 + (C0.double() if acc else 0)
+    assert bool(((dma.double() - ref).abs() <= _bound(a64.T, b64) + 1e-5).all())
+    # a 256-tile launch and a 128-tile launch choose other k-splits: equal up to the order of the fp32 slab sums
+    assert float((dma - small).abs().max()) <= 2 * float(_bound(a64.T, b64).max()) + 1e-5
+    if cs:
+        assert torch.equal(dma_cs, again_cs)
+        bound = 2.0 ** -16 * a64.abs().sum(0) + 1e-6
+        assert bool(((dma_cs.double() - a64.sum(0)).abs() <= bound).all())
+        assert bool(((dma_cs.double() - reg_cs.double()).abs() <= bound).all())
+
+
 def test_opt_in_32_deep_stages_same_bits():
     """XPS_GEMM_BIG_DEEP=1 (32-deep LDS stages with swizzled [x][k] images, read once per process): the direct forms must
     still equal the 128-tile kernels bit for bit.  Own process because the switch is read at first use."""

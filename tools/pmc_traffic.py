@@ -21,11 +21,12 @@ for spec in sys.argv[2:]:
     pat, alg, fcsv, wcsv = parts[0], int(parts[1]), parts[2], parts[3]
     extra = parts[4][1:] if len(parts) > 4 else None
     f, w = per_kernel(fcsv, 'FETCH_SIZE', pat), per_kernel(wcsv, 'WRITE_SIZE', pat)
+    if f is None or w is None:          # (kernel pattern not in the trace: no entry, no TypeError -- ADVICE r3)
+        print(f'pmc_traffic: no dispatch matches {pat!r} in {fcsv} / {wcsv}', file=sys.stderr)
+        continue
     if extra:
         f += per_kernel(fcsv, 'FETCH_SIZE', extra) or 0.0
         w += per_kernel(wcsv, 'WRITE_SIZE', extra) or 0.0
-    if f is None or w is None:
-        continue
     hbm = int((2 * f + w) * 1024)
     out[name] = {'FETCH_SIZE_KB': f, 'WRITE_SIZE_KB': w, 'hbm_bytes_per_launch': hbm, 'algorithmic_bytes': alg, 'ratio': round(hbm / alg, 3)}
 json.dump(out, open(sys.argv[1], 'w'), indent=1)
