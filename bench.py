@@ -48,7 +48,9 @@ PREWARM = {'configs3': 150, 'configs1': 400}
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2 / 16x16x4, 64 FLOP/clk/SIMD
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PMC_FILE = os.path.join(ROOT, 'profiles', 'round3', 'pmc_traffic.json')
+# HBM-side traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): collected OFFLINE by tools/round4_evidence.sh with the
+# kernels of the commit named in the file, not measured inside this run (`roofline.traffic_source` says so in the line)
+PMC_FILES = [os.path.join(ROOT, 'profiles', r, 'pmc_traffic.json') for r in ('round4', 'round3')]
 
 
 def train_flops_per_trial(c):
@@ -78,13 +80,28 @@ def build_model(c, dropout=0.3):
 
 
 def _pmc(key):
-    """HBM-side bytes per launch from the PMC passes kept under profiles/round3 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    separate passes, gfx950 FETCH x2 correction; collected offline by tools/pmc_round3.sh with THIS round's kernels)."""
-    try:
-        with open(PMC_FILE) as f:
-            return json.load(f)[key]['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM-side bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    passes, gfx950 FETCH x2 correction; collected offline by tools/round4_evidence.sh): the newest file that has the key."""
+    for path in PMC_FILES:
+        try:
+            with open(path) as f:
+                return json.load(f)[key]['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def _pmc_source(key):
+    for path in PMC_FILES:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if key in d:
+                return (f"committed PMC profile {os.path.relpath(path, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                        f"FETCH x2 gfx950 correction; kernels of commit {d.get('_commit', 'see profiles/ README')}; not measured in this run)")
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def cpu_model_name():
@@ -230,7 +247,8 @@ def roofline_wgrad(model, c, captured=None):
     traffic = _pmc('gemm_tn_grouped_kernel' + ('' if precision == 'fp32' else '_' + precision))
     bytes_alg = 4 * (K * (2 * 3 * H + 2 * H + In + 2 * H) + 2 * (3 * H * H + 3 * H * In + 6 * H))
     common = {'launch_us': round(dur * 1e6, 1), 'flops_per_launch': flops, 'bytes_per_launch': bytes_alg, 'operands': operands,
-              'traffic': traffic, 'precision': precision,
+              'traffic': traffic, 'traffic_source': _pmc_source('gemm_tn_grouped_kernel' + ('' if precision == 'fp32' else '_' + precision)),
+              'precision': precision,
               'random_operands': {'launch_us': round(dur_rand * 1e6, 1)}}
     if precision == 'fp32':
         out = {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel (fp32 MFMA 128x128x16 tile; encoder layer-1 weight '
@@ -283,10 +301,15 @@ def roofline_cluster(model, c, dev):
     tr_b, tr_f = _pmc('gru_cluster_bwd_kernel' + sfx), _pmc('gru_cluster_fwd_kernel' + sfx)
     # the largest GEMM of the step beside it: dW_ih of encoder layer 1 (3H x 2H x T'B), the 256-tile TN kernel incl. its reduce
     K, In = Tp * B, 2 * H
+    from cross_patient_speech_decoding_amd._lib import rowmap
     A = torch.randn(K, 3 * H, device=dev) * 0.1
     Bm = torch.randn(K, In, device=dev)
+    ofmt = 1 if split else 0                  # bf16x3 mode: both operands reach this GEMM as XPS_FMT_SPLIT4 images in the step (dgi from
+    if ofmt:                                  # the BPTT kernel, the layer input from the dropout pass): the LDS-DMA k loop
+        A, Bm = XF.split4(A), XF.split4(Bm)
     Cw, cb = torch.empty(3 * H, In, device=dev), torch.empty(3 * H, device=dev)
-    t_g = _event_time(lambda: XF.gemm_tn_grouped([XF.tn_problem(A, Bm, Cw, 3 * H, In, K, colsum_out=cb)], dev), iters=10)
+    t_g = _event_time(lambda: XF.gemm_tn_grouped([XF.tn_problem(A, Bm, Cw, 3 * H, In, K, ra=rowmap(3 * H, fmt=ofmt), rb=rowmap(In, fmt=ofmt),
+                                                                colsum_out=cb)], dev), iters=20)
     fl_g = 2.0 * 3 * H * In * K
     issued = 3 if sfx else 1
     peak = BF16_MFMA_PEAK_TFLOPS if sfx else F32_MFMA_PEAK_TFLOPS
@@ -295,13 +318,15 @@ def roofline_cluster(model, c, dev):
            'achieved': round(by_b / t_b / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by_b / t_b / 1e9 / HBM_PEAK_GBS, 4),
            'launch_us': round(t_b * 1e6, 1), 'bytes_per_launch': by_b, 'flops_per_launch': fl_rec, 'traffic': tr_b,
            'traffic_ratio': round(tr_b / by_b, 3) if tr_b else None,
+           'traffic_source': _pmc_source('gru_cluster_bwd_kernel' + sfx),
            'precision': XF.get_gemm_precision(), 'operands': 'random normal operands of the step\'s shapes',
            'also': [{'kernel': 'gru_cluster_fwd_kernel (same layer, forward, gates saved)', 'bound': 'hbm',
                      'achieved': round(by_f / t_f / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(by_f / t_f / 1e9 / HBM_PEAK_GBS, 4), 'launch_us': round(t_f * 1e6, 1),
                      'bytes_per_launch': by_f, 'flops_per_launch': fl_rec, 'traffic': tr_f,
                      'traffic_ratio': round(tr_f / by_f, 3) if tr_f else None},
-                    {'kernel': 'gemm_big_tn_kernel + reduce (dW_ih of encoder layer 1: 1536 x 1024 x 40960, 256 x 256 tiles)', 'bound': 'mfma',
+                    {'kernel': 'gemm_big_tn_kernel + reduce (dW_ih of encoder layer 1: 1536 x 1024 x 40960, 256 x 256 tiles' +
+                               (', XPS_FMT_SPLIT4 operands: LDS-DMA k loop)' if ofmt else ')'), 'bound': 'mfma',
                      'achieved': round(issued * fl_g / t_g / 1e12, 1), 'peak': peak, 'unit': 'TFLOP/s (issued MFMA work)',
                      'frac': round(issued * fl_g / t_g / 1e12 / peak, 4), 'launch_us': round(t_g * 1e6, 1), 'flops_per_launch': fl_g,
                      'algorithmic_tflops': round(fl_g / t_g / 1e12, 1),
@@ -365,23 +390,31 @@ def workload_record(name, dev, steps, warm, with_roofline=True):
 
 
 def fp32_record(name, dev, steps, warm):
-    """The headline workload with the matrix kernels in exact-fp32 MFMA mode (the reference's own arithmetic), priced
-    against the 157.3 TFLOP/s fp32 matrix peak."""
+    """The headline workload with the matrix kernels in exact-fp32 MFMA mode (the reference's own arithmetic): the
+    precision-MATCHED number.  Whole step priced against the 157.3 TFLOP/s fp32 matrix peak; `roofline` = the same dominant-kernel
+    record as the headline's, measured in this mode (configs[3]: the cluster BPTT launch -- same algorithmic bytes, fp32
+    recurrent products -- with the forward launch and the largest fp32-MFMA GEMM beside it)."""
     from cross_patient_speech_decoding_amd.nn_models import functional as XF
     c = WORKLOADS[name]
     old = XF.get_gemm_precision()
     XF.set_gemm_precision('fp32')
+    roof = None
     try:
-        _, step = _make_step(c, dev, 0)
+        model, step = _make_step(c, dev, 0)
         dt = _timed_steps(step, steps, warm)
         XF.check_gru_status()
+        if name == 'configs3':
+            roof = roofline_cluster(model, c, dev)
     finally:
         XF.set_gemm_precision(old)
     fl = train_flops_per_trial(c)
     tf = c['trials_per_gpu'] / dt * fl / 1e12
-    return {'workload': name, 'dtype': 'f32', 'ms_per_step': round(dt * 1e3, 3), 'value': round(c['trials_per_gpu'] / dt, 1),
-            'unit': 'trials/s', 'model_tflops': round(tf, 2), 'peak_tflops': F32_MFMA_PEAK_TFLOPS,
-            'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4), 'steps': steps, 'warmup': warm}
+    out = {'workload': name, 'dtype': 'f32', 'ms_per_step': round(dt * 1e3, 3), 'value': round(c['trials_per_gpu'] / dt, 1),
+           'unit': 'trials/s', 'model_tflops': round(tf, 2), 'peak_tflops': F32_MFMA_PEAK_TFLOPS,
+           'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4), 'steps': steps, 'warmup': warm}
+    if roof is not None:
+        out['roofline'] = roof
+    return out
 
 
 def alignment_record(dev):
@@ -658,7 +691,7 @@ def main():
                 other = 'configs1' if name == 'configs3' else 'configs3'
                 # sub-records never cost the headline line: a failure is reported in place of the record
                 for key, fn in ((other, lambda: workload_record(other, dev, 200 if other == 'configs1' else 100, 20)),
-                                ('fp32', (lambda: fp32_record(name, dev, 30 if name == 'configs3' else 100, 10)) if precision != 'fp32' else None),
+                                ('fp32', (lambda: fp32_record(name, dev, 100, 10)) if precision != 'fp32' else None),
                                 ('alignment', lambda: alignment_record(dev)),
                                 ('realtime', lambda: realtime_record(dev)),
                                 ('dp_rehearsal', lambda: dp_rehearsal_record(name, dev, 100, 30))):

@@ -135,6 +135,12 @@ SIGNATURES = {
     'xps_svm_smo_f64_max_points': (_sz, []),
     'xps_svm_smo_f64': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp]),
     'xps_dgemm_small': (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp]),
+    'xps_dgemm_splitk_workspace': (_sz, [_i, _i, _i]),
+    'xps_dgemm_splitk': (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    'xps_lanczos_f64_workspace': (_sz, [_i]),
+    'xps_lanczos_f64': (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xps_cheb_filter_f64_workspace': (_sz, [_i, _i]),
+    'xps_cheb_filter_f64': (_i, [_vp, _i64, _i, _vp, _i, _i, _d, _d, _d, _vp, _vp, _sz, _vp]),
 }
 
 

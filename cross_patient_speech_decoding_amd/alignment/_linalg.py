@@ -5,6 +5,8 @@ f64 MFMA, Jacobi eigen/singular decompositions, batched transform apply — runs
 Host numpy only sorts / normalises / sign-fixes the small (d x d) results and builds index
 lists; there is no CPU fallback for the kernels.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -118,9 +120,29 @@ def dgemm(A, B, ta=False, tb=False):
     K = A.shape[0] if ta else A.shape[1]
     N = B.shape[0] if tb else B.shape[1]
     C = torch.empty(M, N, dtype=F64, device=A.device)
+    if K >= 512 and ((M + 63) // 64) * ((N + 63) // 64) <= 64:
+        # few output tiles, long contraction (the skinny products of the subspace iteration): split-K slabs + one reduce
+        nb = lib().xps_dgemm_splitk_workspace(M, N, K)
+        ws = _ws(nb)
+        call('xps_dgemm_splitk', A.data_ptr(), A.stride(0), int(ta), B.data_ptr(), B.stride(0), int(tb), C.data_ptr(), N,
+             M, N, K, ws.data_ptr(), nb, _stream())
+        return C
     call('xps_dgemm_small', A.data_ptr(), A.stride(0), int(ta), B.data_ptr(), B.stride(0), int(tb), C.data_ptr(), N,
          M, N, K, _stream())
     return C
+
+
+def cheb_filter(Cd, A, deg, c, e, sigma1):
+    """Y_deg of the scaled Chebyshev recurrence on the block A (n x m) with the symmetric operator Cd -- `deg` products
+    enqueued by ONE library call (xps_cheb_filter_f64: per product a split-K launch + a reduce that applies the three-term update)."""
+    A = A.contiguous()
+    n, m = A.shape
+    out = torch.empty_like(A)
+    nb = lib().xps_cheb_filter_f64_workspace(n, m)
+    ws = _ws(nb)
+    call('xps_cheb_filter_f64', Cd.data_ptr(), Cd.stride(0), n, A.data_ptr(), m, int(deg), float(c), float(e), float(sigma1),
+         out.data_ptr(), ws.data_ptr(), nb, _stream())
+    return out
 
 
 def apply(X, W, mean=None, out_f32=False):
@@ -291,22 +313,19 @@ def _lanczos_bounds(C, steps=24):
     reorthogonalisation: only the two extreme Ritz values are used): extreme Ritz value -/+ its residual bound
     |beta_j s_j|, widened by 2 % of the width.  The recurrence runs on the device without synchronising; the
     steps x steps tridiagonal matrix is diagonalised by the small device Jacobi."""
+    C = C.contiguous()
     n = C.shape[0]
     steps = min(steps, n)
     dev = C.device
     v = torch.sin(0.7 * torch.arange(1, n + 1, dtype=F64, device=dev)) + 0.01
-    v = (v / torch.linalg.vector_norm(v)).reshape(n, 1)
-    vp = torch.zeros_like(v)
-    beta = torch.zeros((), dtype=F64, device=dev)
-    al, be = [], []
-    for _ in range(steps):
-        w = dgemm(C, v) - beta * vp
-        a = (w * v).sum()
-        w = w - a * v
-        beta = torch.linalg.vector_norm(w)
-        al.append(a); be.append(beta)
-        vp, v = v, w / beta
-    ab = torch.stack(al + be).cpu().numpy()
+    v = (v / torch.linalg.vector_norm(v)).contiguous()
+    ab_d = torch.empty(2 * steps, dtype=F64, device=dev)
+    nb = lib().xps_lanczos_f64_workspace(n)
+    ws = _ws(nb)
+    # (the whole recurrence is enqueued by one library call: 2 launches per step; the Python loop paid ~10 launches per step)
+    call('xps_lanczos_f64', C.data_ptr(), C.stride(0), n, steps, v.data_ptr(), ab_d.data_ptr(), ab_d.data_ptr() + 8 * steps,
+         ws.data_ptr(), nb, _stream())
+    ab = ab_d.cpu().numpy()
     a, b = ab[:steps], ab[steps:]
     if not np.isfinite(ab).all():
         return None
@@ -320,9 +339,45 @@ def _lanczos_bounds(C, steps=24):
     return lo - pad, hi + pad
 
 
+def _orthonormal_columns_cholqr3(Y):
+    """Orthonormal basis of the column span of Y (n x m, m << n) by SHIFTED CHOLESKY QR in three passes (Fukaya, Kannan,
+    Nakatsukasa, Yamamoto, Yanagisawa 2020) on the column-normalised block: pass 1 factors G + s I with
+    s = 11 (n m + m (m + 1)) eps ||G|| (a factor exists whatever the condition number; it brings the block to a condition of
+    ~sqrt(1 / eps) at worst), passes 2 and 3 are plain Cholesky QR.  Per pass: Gram matrix and the triangular solve as f64 MFMA
+    products on the device, the m x m (<= 48 x 48) factor on the host.  ~0.4 ms against ~1.3 ms for the one-sided Jacobi on the
+    tall block (three workgroups busy).  None when a factorisation fails or the result is not orthonormal (-> the Jacobi route)."""
+    n, m = Y.shape
+    s = torch.linalg.vector_norm(Y, dim=0)
+    smin, smax = (float(x) for x in torch.stack([s.min(), s.max()]).cpu())
+    if not np.isfinite(smax) or smin <= 0.0:
+        return None
+    A = (Y / s).contiguous()
+    for p in range(3):
+        G = dgemm(A, A, ta=True).cpu().numpy()
+        G = 0.5 * (G + G.T)
+        if not np.isfinite(G).all():
+            return None
+        if p == 0:
+            G = G + (11.0 * (n * m + m * (m + 1)) * EPS * float(np.linalg.norm(G, 2))) * np.eye(m)
+        try:
+            Linv = np.linalg.inv(np.linalg.cholesky(G))
+        except np.linalg.LinAlgError:
+            return None
+        A = dgemm(A, to_device(np.ascontiguousarray(Linv.T)))
+    G = dgemm(A, A, ta=True).cpu().numpy()
+    if not np.isfinite(G).all() or np.abs(G - np.eye(m)).max() > 1e-12:
+        return None
+    return A
+
+
 def _orthonormal_columns(Y):
-    """Orthonormal basis of the column span of Y (n x m device matrix, m << n) by one-sided Jacobi on Y itself (no Gram
-    matrix: a filtered block whose columns differ in size by 1e7 keeps its small directions).  None if rank was lost."""
+    """Orthonormal basis of the column span of Y (n x m device matrix, m << n).  Shifted Cholesky QR (above) where it
+    succeeds; else -- and always with XPS_TOPK_ORTHO=jacobi -- one-sided Jacobi on Y itself (no Gram matrix: a filtered block
+    whose columns differ in size by 1e7 keeps its small directions).  None if rank was lost."""
+    if os.environ.get('XPS_TOPK_ORTHO', 'chol') != 'jacobi':
+        Q = _orthonormal_columns_cholqr3(Y)
+        if Q is not None:
+            return Q
     Wt = Y.t().contiguous()
     m, n = Wt.shape
     _jacobi(Wt, m, n, want_v=False)
@@ -331,6 +386,19 @@ def _orthonormal_columns(Y):
     if not np.isfinite(smax) or smin <= smax * 1e-13:
         return None
     return (Wt / s[:, None]).t().contiguous()
+
+
+def _reorthonormalise(A):
+    """Orthonormal basis of the span of an ALREADY nearly orthonormal block (the purge of the locked directions moved it by
+    rounding errors only): Cholesky QR -- Gram matrix on the device (f64 MFMA), its 45 x 45 Cholesky factor on the host, one
+    product -- instead of a second one-sided Jacobi on the tall block (~1 ms each).  The Gram matrix of such a block is
+    within rounding of the identity, so squaring the condition number costs nothing; anything else takes the robust route."""
+    G = dgemm(A, A, ta=True).cpu().numpy()
+    G = 0.5 * (G + G.T)
+    if not np.isfinite(G).all() or np.abs(G - np.eye(G.shape[0])).max() > 1e-3:
+        return _orthonormal_columns(A)
+    Linv = np.linalg.inv(np.linalg.cholesky(G))                    # G = L L^T  ->  A L^-T is orthonormal
+    return dgemm(A, to_device(np.ascontiguousarray(Linv.T)))
 
 
 def eigh_sym_top(C, k, tol=2e-14, max_outer=40, max_degree=40, stats=None):
@@ -384,14 +452,8 @@ def eigh_sym_top(C, k, tol=2e-14, max_outer=40, max_degree=40, stats=None):
                 break
             deg = int(np.log(2e7) / np.arccosh(xtop))
             deg = max(2, min(max_degree, deg))
-            sigma = e / (float(theta[0]) - c)
-            sigma1 = sigma
-            Y = op(A).sub_(A, alpha=c).mul_(sigma1 / e)
-            Vp = A
-            for _ in range(1, deg):
-                sigma2 = 1.0 / (2.0 / sigma1 - sigma)
-                Yn = op(Y).sub_(Y, alpha=c).mul_(2.0 * sigma2 / e).sub_(Vp, alpha=sigma * sigma2)
-                Vp, Y, sigma = Y, Yn, sigma2
+            sigma1 = e / (float(theta[0]) - c)
+            Y = cheb_filter(Cd, A, deg, c, e, sigma1)       # (the whole recurrence: one library call, 2 launches per product)
             nprod += deg
             if outer > 12 or nprod > 260:              # a spectrum this method is not made for: stop paying for it
                 break
@@ -399,7 +461,7 @@ def eigh_sym_top(C, k, tol=2e-14, max_outer=40, max_degree=40, stats=None):
             if A is None:
                 break
             if L is not None:
-                A = _orthonormal_columns(purge(A))
+                A = _reorthonormalise(purge(A))
                 if A is None:
                     break
         # Rayleigh-Ritz of the (deflated) operator on the active block; H + shift is positive definite

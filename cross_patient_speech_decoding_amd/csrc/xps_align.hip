@@ -656,6 +656,197 @@ extern "C" int xps_dgemm_small(const double* A, int64_t lda, int ta, const doubl
     return XPS_OK;
 }
 
+// ---- skinny float64 products: few output tiles, long contraction (the subspace iteration of the MCCA eigensolve: a 1024 x 1024
+// matrix against a 1024 x 45 block was ONE launch of 16 blocks, 80-110 us) -> split-K slabs + one reduce, deterministic ----
+static int dgemm_splits(int M, int N, int K) {
+    const long long tiles = (long long)cdiv(M, DM) * cdiv(N, DN);
+    long long s = (256 + tiles - 1) / tiles;
+    const long long maxs = (K + 4 * DK - 1) / (4 * DK);
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+// out = alpha * sum_z slab_z + beta * Y + gamma * Vp   (Vp may be null); element-wise, row-major with leading dimension N
+static __global__ void slab_reduce64_axpy(const double* __restrict__ slabs, int splits, long long slab_stride, const double* __restrict__ Y,
+                                   const double* __restrict__ Vp, double* __restrict__ out, long long total, double alpha, double beta,
+                                   double gamma) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += slabs[(long long)z * slab_stride + idx];
+    double v = alpha * s;
+    if (Y) v += beta * Y[idx];
+    if (Vp) v += gamma * Vp[idx];
+    out[idx] = v;
+}
+
+extern "C" size_t xps_dgemm_splitk_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 16;
+    return (size_t)dgemm_splits(M, N, K) * M * N * sizeof(double) + 16;
+}
+
+// C = op(A) op(B) like xps_dgemm_small, the contraction split over workgroups (deterministic slabs in `workspace`)
+extern "C" int xps_dgemm_splitk(const double* A, int64_t lda, int ta, const double* B, int64_t ldb, int tb, double* C, int64_t ldc,
+                                int M, int N, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(A && B && C && M >= 1 && N >= 1 && K >= 1, "bad argument");
+    if (!workspace || workspace_bytes < xps_dgemm_splitk_workspace(M, N, K) || !aligned8(workspace)) {
+        xps_set_error("xps_dgemm_splitk: workspace too small or misaligned");
+        return XPS_E_WORKSPACE;
+    }
+    const int splits = dgemm_splits(M, N, K);
+    const int kchunk = ((cdiv(K, splits) + DK - 1) / DK) * DK;
+    Mat64 a{A, (long long)lda, nullptr, 0}, b{B, (long long)ldb, nullptr, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const long long slab = (long long)M * N;
+    int rc;
+    if (!ta && !tb) rc = launch_gemm64<true, false>(a, b, workspace, N, 0, M, N, K, splits, kchunk, slab, st);
+    else if (!ta && tb) rc = launch_gemm64<true, true>(a, b, workspace, N, 0, M, N, K, splits, kchunk, slab, st);
+    else if (ta && !tb) rc = launch_gemm64<false, false>(a, b, workspace, N, 0, M, N, K, splits, kchunk, slab, st);
+    else rc = launch_gemm64<false, true>(a, b, workspace, N, 0, M, N, K, splits, kchunk, slab, st);
+    if (rc) { xps_set_error("xps_dgemm_splitk: launch failed"); return XPS_E_HIP; }
+    hipLaunchKernelGGL(slab_reduce64, dim3(cdiv(slab, 256)), dim3(256), 0, st, (const double*)workspace, splits, slab, C, (long long)ldc, M, N);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+// Chebyshev filter of a block (Zhou & Saad's scaled three-term recurrence; alignment/_linalg.py: eigh_sym_top):
+//   Y_1 = (C A - c A) sigma_1 / e ;  Y_{j+1} = (C Y_j - c Y_j) 2 sigma_{j+1} / e - sigma_j sigma_{j+1} Y_{j-1},
+//   sigma_{j+1} = 1 / (2 / sigma_1 - sigma_j), deg products in all, ONE host call: per product a split-K launch and a reduce that
+// applies the recurrence (the Python loop paid ~0.2 ms of host + launch time per product, 129 products per 8-view MCCA fit).
+// C: n x n symmetric (leading dimension ldc); A, out: n x m row-major (leading dimension m); out may not alias A.
+extern "C" size_t xps_cheb_filter_f64_workspace(int n, int m) {
+    if (n <= 0 || m <= 0) return 16;
+    return ((size_t)dgemm_splits(n, m, n) + 3) * n * m * sizeof(double) + 16;
+}
+
+extern "C" int xps_cheb_filter_f64(const double* C, int64_t ldc, int n, const double* A, int m, int deg, double c, double e, double sigma1,
+                                   double* out, void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(C && A && out && n >= 1 && m >= 1 && deg >= 1 && e > 0.0 && out != A, "bad argument");
+    if (!workspace || workspace_bytes < xps_cheb_filter_f64_workspace(n, m) || !aligned8(workspace)) {
+        xps_set_error("xps_cheb_filter_f64: workspace too small or misaligned");
+        return XPS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = dgemm_splits(n, m, n);
+    const int kchunk = ((cdiv(n, splits) + DK - 1) / DK) * DK;
+    const long long slab = (long long)n * m;
+    double* slabs = (double*)workspace;
+    double* ring[3] = {slabs + (long long)splits * slab, slabs + (long long)(splits + 1) * slab, slabs + (long long)(splits + 2) * slab};
+    Mat64 cm{C, (long long)ldc, nullptr, 0};
+    const double* Y = A;
+    const double* Vp = nullptr;
+    double sigma = sigma1;
+    for (int j = 0; j < deg; ++j) {
+        double alpha, gamma = 0.0;
+        if (j == 0) alpha = sigma1 / e;
+        else {
+            const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+            alpha = 2.0 * sigma2 / e;
+            gamma = -sigma * sigma2;
+            sigma = sigma2;
+        }
+        Mat64 ym{Y, (long long)m, nullptr, 0};
+        if (launch_gemm64<true, false>(cm, ym, slabs, m, 0, n, m, n, splits, kchunk, slab, st)) {
+            xps_set_error("xps_cheb_filter_f64: launch failed");
+            return XPS_E_HIP;
+        }
+        double* dst = (j == deg - 1) ? out : ring[j % 3];
+        hipLaunchKernelGGL(slab_reduce64_axpy, dim3(cdiv(slab, 256)), dim3(256), 0, st, (const double*)slabs, splits, slab, Y, Vp, dst, slab,
+                           alpha, -c * alpha, gamma);
+        Vp = Y;
+        Y = dst;
+    }
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
+// One Lanczos step behind the split-K product slabs = C v (no reorthogonalisation; alignment/_linalg.py: _lanczos_bounds):
+//   w = sum_z slab_z - beta_prev vp;  a = w . v;  w -= a v;  b = ||w||;  vp = v;  v = w / b;  alpha[j] = a, beta[j] = b.
+// ONE workgroup (n is at most a few thousand): fixed reduction order, deterministic.
+static __global__ __launch_bounds__(1024) void lanczos_step_kernel(const double* __restrict__ slabs, int splits, int n, double* __restrict__ v,
+                                                                   double* __restrict__ vp, double* __restrict__ w, double* __restrict__ alpha,
+                                                                   double* __restrict__ beta, int j) {
+    __shared__ double red[16];
+    __shared__ double bc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto block_sum = [&](double x) -> double {
+        x = wave_sum(x);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 16; ++i) s += red[i];
+            bc = s;
+        }
+        __syncthreads();
+        return bc;
+    };
+    const double bprev = j > 0 ? beta[j - 1] : 0.0;
+    double dot = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        double s = 0.0;
+        for (int z = 0; z < splits; ++z) s += slabs[(long long)z * n + i];
+        s -= bprev * vp[i];
+        w[i] = s;
+        dot += s * v[i];
+    }
+    const double a = block_sum(dot);
+    double nn = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        const double x = w[i] - a * v[i];
+        w[i] = x;
+        nn += x * x;
+    }
+    const double b = sqrt(block_sum(nn));
+    for (int i = tid; i < n; i += 1024) {
+        vp[i] = v[i];
+        v[i] = w[i] / b;
+    }
+    if (tid == 0) { alpha[j] = a; beta[j] = b; }
+}
+
+extern "C" size_t xps_lanczos_f64_workspace(int n) {
+    if (n <= 0) return 16;
+    return ((size_t)dgemm_splits(n, 1, n) + 3) * n * sizeof(double) + 16;
+}
+
+// `steps` Lanczos steps on the symmetric n x n matrix C from the start vector v0 (normalised here): alpha[steps], beta[steps]
+// (device arrays) = the diagonal / off-diagonal of the tridiagonal matrix; enqueued by this one call (2 launches per step).
+extern "C" int xps_lanczos_f64(const double* C, int64_t ldc, int n, int steps, const double* v0, double* alpha, double* beta,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(C && v0 && alpha && beta && n >= 1 && steps >= 1, "bad argument");
+    if (!workspace || workspace_bytes < xps_lanczos_f64_workspace(n) || !aligned8(workspace)) {
+        xps_set_error("xps_lanczos_f64: workspace too small or misaligned");
+        return XPS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = dgemm_splits(n, 1, n);
+    const int kchunk = ((cdiv(n, splits) + DK - 1) / DK) * DK;
+    double* slabs = (double*)workspace;
+    double* v = slabs + (long long)splits * n;
+    double* vp = v + n;
+    double* w = vp + n;
+    if (hipMemcpyAsync(v, v0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemsetAsync(vp, 0, (size_t)n * sizeof(double), st) != hipSuccess) {
+        xps_set_error("xps_lanczos_f64: copy failed");
+        return XPS_E_HIP;
+    }
+    Mat64 cm{C, (long long)ldc, nullptr, 0};
+    for (int j = 0; j < steps; ++j) {
+        Mat64 vm{v, 1, nullptr, 0};
+        if (launch_gemm64<true, false>(cm, vm, slabs, 1, 0, n, 1, n, splits, kchunk, (long long)n, st)) {
+            xps_set_error("xps_lanczos_f64: launch failed");
+            return XPS_E_HIP;
+        }
+        hipLaunchKernelGGL(lanczos_step_kernel, dim3(1), dim3(1024), 0, st, (const double*)slabs, splits, n, v, vp, w, alpha, beta, j);
+    }
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
 extern "C" size_t xps_jacobi_f64_workspace(int n) { (void)n; return 16; }
 
 namespace {

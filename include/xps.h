@@ -432,6 +432,23 @@ int xps_svm_smo_f64(const double* K, int64_t ldk, const int* idx, const int* off
 /* small dense float64 GEMM  C = op(A) op(B)  (row-major, op = transpose flag) */
 int xps_dgemm_small(const double* A, int64_t lda, int ta, const double* B, int64_t ldb, int tb,
                     double* C, int64_t ldc, int M, int N, int K, void* stream);
+/* the same product with the contraction split over workgroups (few output tiles, long K: the skinny products of the MCCA
+ * eigensolve); deterministic partial slabs in `workspace` (xps_dgemm_splitk_workspace bytes), one reduce launch */
+size_t xps_dgemm_splitk_workspace(int M, int N, int K);
+int xps_dgemm_splitk(const double* A, int64_t lda, int ta, const double* B, int64_t ldb, int tb, double* C, int64_t ldc,
+                     int M, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
+/* Chebyshev filter of an n x m block A (row-major, leading dimension m) by the symmetric n x n matrix C: the scaled three-term
+ * recurrence of the top-k eigensolve behind AlignMCCA.fit (alignment/AlignMCCA.py:152-153 hands the generalised eigenproblem
+ * to mvlearn / scipy.linalg.eigh): Y_1 = (C A - c A) sigma1 / e, Y_{j+1} = (C Y_j - c Y_j) 2 sigma_{j+1} / e - sigma_j sigma_{j+1} Y_{j-1},
+ * sigma_{j+1} = 1 / (2 / sigma1 - sigma_j); `deg` products, all enqueued by this one call; out (n x m) receives Y_deg.       */
+/* `steps` Lanczos steps (no reorthogonalisation) on the symmetric n x n matrix C from v0 / ||v0||: alpha[steps], beta[steps]
+ * (device arrays) = diagonal / off-diagonal of the tridiagonal matrix whose extreme Ritz values bound the spectrum for the filter */
+size_t xps_lanczos_f64_workspace(int n);
+int xps_lanczos_f64(const double* C, int64_t ldc, int n, int steps, const double* v0, double* alpha, double* beta,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t xps_cheb_filter_f64_workspace(int n, int m);
+int xps_cheb_filter_f64(const double* C, int64_t ldc, int n, const double* A, int m, int deg, double c, double e, double sigma1,
+                        double* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Training-set augmentations on (trial x time x channel) fp32 tensors           */
