@@ -132,6 +132,7 @@ SIGNATURES = {
     'xps_aug_scale_f32': (_i, [_vp, _vp, _i64, _f, _vp]),
     'xps_aug_jitter_f32': (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
     'xps_aug_time_warp_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'xps_rbf_from_gram_f64': (_i, [_vp, _i64, _vp, _vp, _i, _i, _d, _vp, _i64, _vp]),
     'xps_svm_smo_f64_max_points': (_sz, []),
     'xps_svm_smo_f64': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp]),
     'xps_dgemm_small': (_i, [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp]),

@@ -168,6 +168,30 @@ __global__ __launch_bounds__(SVM_THREADS) void svm_smo_kernel(const double* __re
 
 }  // namespace
 
+namespace {
+// RBF kernel matrix from a Gram matrix: K[i][j] = exp(-gamma (na[i] + nb[j] - 2 G[i][j])) -- libsvm's own formula
+// (svm.cpp Kernel::kernel_rbf: x_square[i] + x_square[j] - 2 dot(x[i], x[j])), element-wise on the device
+__global__ __launch_bounds__(256) void rbf_from_gram_kernel(const double* __restrict__ G, long long ldg, const double* __restrict__ na,
+                                                            const double* __restrict__ nb, int m, int n, double gamma,
+                                                            double* __restrict__ K, long long ldk) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)m * n) return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    K[(long long)i * ldk + j] = exp(-gamma * (na[i] + nb[j] - 2.0 * G[(long long)i * ldg + j]));
+}
+
+}  // namespace
+
+extern "C" int xps_rbf_from_gram_f64(const double* G, int64_t ldg, const double* na, const double* nb, int m, int n, double gamma,
+                                     double* K, int64_t ldk, void* stream) {
+    XPS_CHECK_ARG(G && na && nb && K && m >= 0 && n >= 0 && ldg >= n && ldk >= n && gamma >= 0.0, "bad argument");
+    if (m == 0 || n == 0) return XPS_OK;
+    hipLaunchKernelGGL(rbf_from_gram_kernel, dim3(cdiv((long long)m * n, 256)), dim3(256), 0, (hipStream_t)stream, G, (long long)ldg, na, nb, m, n,
+                       gamma, K, (long long)ldk);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
 // the launch asks for max_points * 28 + 64 bytes of dynamic LDS beside ~112 bytes of static LDS (budgeted as 128) under the
 // limit of 160 KiB - 1 KiB raised below: the largest problem that LAUNCHES (5813 / 5814 passed the check and failed at launch)
 constexpr size_t SVM_LDS_LIMIT = 160 * 1024 - 1024, SVM_LDS_FIXED = 64 + 128;

@@ -426,6 +426,10 @@ int xps_apply_f64(const void* X, int x_is_f32, int64_t ldx, const double* mean, 
  * SMO (WSS 2, eps stopping rule, calculate_rho) with alpha / gradient in LDS (max_points = the largest problem, at most
  * xps_svm_smo_f64_max_points()); cbound[off[p] + t] = the point's upper bound C * sample_weight (> 0: libsvm drops zero-weight
  * points before training, so does the caller).  Outputs: alpha[off[p] + t], rho[p], iterations[p].                          */
+/* RBF kernel matrix from a Gram matrix (SVC(kernel='rbf'): scripts/aligned_decode_svm_ncv.py:313-317):
+ * K[i][j] = exp(-gamma (na[i] + nb[j] - 2 G[i][j])), G = A B^T (m x n), na / nb the squared row norms of A / B -- libsvm's formula */
+int xps_rbf_from_gram_f64(const double* G, int64_t ldg, const double* na, const double* nb, int m, int n, double gamma,
+                          double* K, int64_t ldk, void* stream);
 size_t xps_svm_smo_f64_max_points(void);
 int xps_svm_smo_f64(const double* K, int64_t ldk, const int* idx, const int* off, const int* npos, int nprob, int max_points,
                     const double* cbound, double eps, int max_iter, double* alpha, double* rho, int* iterations, void* stream);

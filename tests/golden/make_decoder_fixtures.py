@@ -45,5 +45,23 @@ if __name__ == '__main__':
         out[f'{name}_pred'] = dec.decoder.predict(out[f'{name}_Xtest'])
         out[f'{name}_acc'] = np.mean(out[f'{name}_pred'] == y1[te])
         print(name, X_p.shape, out[f'{name}_acc'])
+    # the nested-CV / sub-sampling scripts' decoder (scripts/aligned_decode_svm_ncv.py:313-321): an RBF SVC with balanced class
+    # weights behind DimRedReshape, inside crossPtDecoder_sepAlign; deterministic (no bagging): decision values are stored too
+    from sklearn.decomposition import PCA                   # noqa: E402
+    from sklearn.pipeline import make_pipeline              # noqa: E402
+    from decomposition.DimRedReshape import DimRedReshape   # noqa: E402
+    clf = make_pipeline(DimRedReshape(PCA), SVC(kernel='rbf', class_weight='balanced'))
+    dec = crossPtDecoder_sepAlign(cross, clf, AlignCCA, n_comp=0.9)
+    X_p, y_p = dec.preprocess_train(Xt[tr], y1[tr], y_align=yt[tr])
+    dec.decoder.fit(X_p, y_p)
+    X_te = dec.preprocess_test(Xt[te])
+    out['rbf_Xpool'], out['rbf_ypool'], out['rbf_Xtest'] = X_p, y_p, X_te
+    out['rbf_pred'] = dec.decoder.predict(X_te)
+    out['rbf_dec_ovr'] = dec.decoder.decision_function(X_te)
+    svc = dec.decoder[-1]
+    out['rbf_gamma'] = np.float64(svc._gamma)
+    out['rbf_class_weight'] = svc.class_weight_
+    out['rbf_acc'] = np.mean(out['rbf_pred'] == y1[te])
+    print('rbf', X_p.shape, out['rbf_acc'], float(svc._gamma), svc.class_weight_)
     np.savez_compressed(os.path.join(HERE, 'decoders_cfg1.npz'), **out)
     print(os.path.getsize(os.path.join(HERE, 'decoders_cfg1.npz')))

@@ -105,7 +105,7 @@ def test_hip_svc_equals_libsvm(n, d, k, C):
     X, y = X[perm], y[perm]
     Xte = np.vstack([centers[c] + rng.standard_normal((20, d)) for c in range(k)])
     ref = SVC(kernel='linear', C=C, decision_function_shape='ovo').fit(X, y)
-    dev = DeviceSVC(kernel='linear', C=C).fit(X, y)
+    dev = DeviceSVC(kernel='linear', C=C, decision_function_shape='ovo').fit(X, y)
     np.testing.assert_array_equal(dev.classes_, ref.classes_)
     d_ref = ref.decision_function(Xte)
     d_dev = dev.decision_function(Xte)
@@ -122,4 +122,86 @@ def test_hip_svc_equals_libsvm(n, d, k, C):
     assert bag.predict(Xte).shape == (20 * k,)
     assert DeviceSVC().set_params(C=2.0).get_params()['C'] == 2.0
     with pytest.raises(NotImplementedError):
-        DeviceSVC(kernel='rbf').fit(X, y)
+        DeviceSVC(kernel='poly').fit(X, y)
+    if k == 2:                                     # sklearn flips coef_ / intercept_ of a binary problem: so does the HIP SVC
+        np.testing.assert_allclose(dev.coef_, ref.coef_, atol=2e-2 * max(1.0, np.abs(ref.coef_).max()))
+        np.testing.assert_allclose(dev.intercept_, ref.intercept_, atol=2e-2 * scale)
+
+
+@pytest.mark.parametrize('n,d,k,C,gamma,cw', [(160, 12, 2, 1.0, 'scale', 'balanced'), (300, 40, 5, 1.0, 'scale', 'balanced'),
+                                             (420, 90, 9, 3.0, 'auto', None), (90, 6, 3, 0.5, 0.2, {1: 2.0, 4: 0.5})])
+def test_hip_svc_rbf_and_class_weights_equal_libsvm(n, d, k, C, gamma, cw):
+    """SVC(kernel='rbf', class_weight='balanced') -- the decoder of scripts/aligned_decode_svm_ncv.py:313-317 and of the four
+    *_subsample.py scripts (:249-261) -- against sklearn's libsvm: gamma ('scale' / 'auto' / a number), the class weights, the
+    one-vs-one decision values to the solvers' tolerance, sklearn's 'ovr' scores (the DEFAULT decision_function_shape: votes +
+    squashed confidences, now computed instead of silently returning the one-vs-one matrix), predictions and accuracy; imbalanced
+    classes, labels that are not 0..k-1, bootstrap multiplicities as sample weights."""
+    from cross_patient_speech_decoding_amd.decoders import SVC as DeviceSVC
+    rng = np.random.default_rng(n * 7 + d)
+    centers = rng.standard_normal((k, d)) * 1.1
+    sizes = rng.multinomial(n - 5 * k, np.linspace(1, 3, k) / np.linspace(1, 3, k).sum()) + 5         # imbalanced
+    X = np.vstack([centers[c] + rng.standard_normal((m, d)) for c, m in enumerate(sizes)])
+    labels = np.arange(k) * 3 + 1
+    y = np.repeat(labels, sizes)
+    perm = rng.permutation(len(y))
+    X, y = X[perm], y[perm]
+    Xte = np.vstack([centers[c] + rng.standard_normal((20, d)) for c in range(k)])
+    yte = np.repeat(labels, 20)
+    sw = rng.integers(0, 3, len(y)).astype(np.float64)                        # (zeros: dropped before training)
+    for weights in (None, sw):
+        ref_o = SVC(kernel='rbf', C=C, gamma=gamma, class_weight=cw, decision_function_shape='ovo').fit(X, y, sample_weight=weights)
+        ref_r = SVC(kernel='rbf', C=C, gamma=gamma, class_weight=cw).fit(X, y, sample_weight=weights)
+        dev_o = DeviceSVC(kernel='rbf', C=C, gamma=gamma, class_weight=cw, decision_function_shape='ovo').fit(X, y, sample_weight=weights)
+        dev_r = DeviceSVC(kernel='rbf', C=C, gamma=gamma, class_weight=cw).fit(X, y, sample_weight=weights)
+        np.testing.assert_array_equal(dev_o.classes_, ref_o.classes_)
+        np.testing.assert_allclose(dev_o._gamma, ref_o._gamma, rtol=1e-12)
+        np.testing.assert_allclose(dev_o.class_weight_, ref_o.class_weight_, rtol=1e-12)
+        d_ref, d_dev = ref_o.decision_function(Xte), dev_o.decision_function(Xte)
+        scale = max(1.0, float(np.abs(d_ref).max()))
+        assert d_dev.shape == d_ref.shape
+        assert np.abs(d_dev - d_ref).max() <= 2e-2 * scale, np.abs(d_dev - d_ref).max()
+        r_ref, r_dev = ref_r.decision_function(Xte), dev_r.decision_function(Xte)
+        assert r_dev.shape == r_ref.shape == ((len(yte),) if k == 2 else (len(yte), k))
+        sure = np.abs(d_ref if d_ref.ndim == 2 else d_ref[:, None]).min(axis=1) > 5e-2 * scale
+        if sure.any():
+            assert np.abs(r_dev - r_ref)[sure].max() <= 2e-2 * scale             # (a vote flips only where a pair value is ~0)
+        if k > 2:                                                                # the 'ovr' rule itself, on identical pair values
+            from cross_patient_speech_decoding_amd.decoders.svm import _ovr_from_ovo
+            np.testing.assert_allclose(_ovr_from_ovo(d_ref, k), r_ref, rtol=0, atol=1e-12)
+        p_ref, p_dev = ref_r.predict(Xte), dev_r.predict(Xte)
+        np.testing.assert_array_equal(p_dev[sure], p_ref[sure])
+        assert np.mean(p_dev == p_ref) >= 0.97
+        assert abs(dev_r.score(Xte, yte) - ref_r.score(Xte, yte)) <= 0.03
+    assert clone(DeviceSVC(kernel='rbf', class_weight='balanced')).get_params()['class_weight'] == 'balanced'
+
+
+def test_rbf_decoder_pipeline_matches_reference_golden(golden_dir):
+    """The reference's own nested-CV decoder (scripts/aligned_decode_svm_ncv.py:313-321: make_pipeline(DimRedReshape(dim_red),
+    SVC(kernel='rbf', class_weight='balanced')) inside crossPtDecoder_sepAlign) run by the reference package on the config-1
+    synthetic patients (tests/golden/make_decoder_fixtures.py): the same pipeline with the device aligner, device PCA and the HIP
+    SVC reproduces its gamma, class weights, 'ovr' decision values and predictions."""
+    import cross_patient_speech_decoding_amd.alignment as A
+    from sklearn.pipeline import make_pipeline
+    from cross_patient_speech_decoding_amd.decoders import SVC as DeviceSVC
+    from cross_patient_speech_decoding_amd.decoders import crossPtDecoder_sepAlign
+    from cross_patient_speech_decoding_amd.decomposition import DimRedReshape
+    g = np.load(os.path.join(golden_dir, 'decoders_cfg1.npz'))
+    Xt, yt, cross = data()
+    y1 = yt[:, 0]
+    tr, te = g['train_idx'], g['test_idx']
+    clf = make_pipeline(DimRedReshape(A.PCA), DeviceSVC(kernel='rbf', class_weight='balanced'))
+    dec = crossPtDecoder_sepAlign(cross, clf, A.AlignCCA, n_comp=0.9)
+    dec.fit(Xt[tr], y1[tr], y_align=yt[tr])
+    svc = dec.decoder[-1]
+    np.testing.assert_allclose(svc.class_weight_, g['rbf_class_weight'], rtol=1e-12)
+    np.testing.assert_allclose(svc._gamma, float(g['rbf_gamma']), rtol=1e-6)          # (1 / (d * var) of the PCA scores: rotation-invariant)
+    X_te = dec.preprocess_test(Xt[te])
+    _close_up_to_sign_per_latent(X_te, g['rbf_Xtest'], 20, 1e-6)
+    ovr = dec.decoder.decision_function(X_te)
+    assert ovr.shape == g['rbf_dec_ovr'].shape
+    assert np.abs(ovr - g['rbf_dec_ovr']).max() <= 2e-2
+    np.testing.assert_array_equal(dec.predict(Xt[te]), g['rbf_pred'])
+    assert abs(dec.score(Xt[te], y1[te]) - float(g['rbf_acc'])) <= 1e-12
+    # the decision values of the SVC alone on the golden pooled features (no aligner / PCA differences in between)
+    alone = DeviceSVC(kernel='rbf', class_weight='balanced').fit(g['rbf_Xpool'], g['rbf_ypool'])
+    assert np.abs(alone.decision_function(g['rbf_Xtest']) - g['rbf_dec_ovr']).max() <= 2e-2
