@@ -205,3 +205,35 @@ def test_rbf_decoder_pipeline_matches_reference_golden(golden_dir):
     # the decision values of the SVC alone on the golden pooled features (no aligner / PCA differences in between)
     alone = DeviceSVC(kernel='rbf', class_weight='balanced').fit(g['rbf_Xpool'], g['rbf_ypool'])
     assert np.abs(alone.decision_function(g['rbf_Xtest']) - g['rbf_dec_ovr']).max() <= 2e-2
+
+
+def test_smo_launches_at_the_lds_resident_limit():
+    """xps_svm_smo_f64_max_points() is derived from the same formula as the launch's LDS request (5813 / 5814 points
+    passed the argument check and then failed AT LAUNCH): a binary problem of exactly that many points launches and returns, one
+    more is refused by the argument check."""
+    import ctypes as C
+    import torch
+    from cross_patient_speech_decoding_amd._lib import XpsError, call, lib
+    from cross_patient_speech_decoding_amd.alignment import _linalg as LA
+    n = int(lib().xps_svm_smo_f64_max_points())
+    assert 5000 < n < 5814 and n * 28 + 64 + 128 <= 160 * 1024 - 1024
+    dev = LA.device()
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(n, 8, generator=g, dtype=torch.float64)
+    X[: n // 2, 0] += 6.0                                    # separable: a handful of iterations
+    Xd = X.to(dev)
+    K = LA.dgemm(Xd, Xd, tb=True)
+    idx = torch.arange(n, dtype=torch.int32, device=dev)
+    off = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    npos = torch.tensor([n // 2], dtype=torch.int32, device=dev)
+    cb = torch.ones(n, dtype=torch.float64, device=dev)
+    alpha = torch.empty(n, dtype=torch.float64, device=dev)
+    rho = torch.empty(1, dtype=torch.float64, device=dev)
+    iters = torch.empty(1, dtype=torch.int32, device=dev)
+    args = (K.data_ptr(), K.stride(0), idx.data_ptr(), off.data_ptr(), npos.data_ptr(), 1)
+    tail = (cb.data_ptr(), 1e-3, 200, alpha.data_ptr(), rho.data_ptr(), iters.data_ptr(), LA._stream())
+    call('xps_svm_smo_f64', *args, n, *tail)
+    torch.cuda.synchronize()
+    assert 0 < int(iters[0]) <= 200 and bool(torch.isfinite(alpha).all()) and float(alpha.sum()) > 0
+    with pytest.raises(XpsError):
+        call('xps_svm_smo_f64', *args, n + 1, *tail)
