@@ -600,13 +600,19 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const float* __restric
     // fmt: bit 0 = A (and A2), bit 1 = B (and B2) are XPS_FMT_SPLIT4 operands; 16-deep stages: fmt == FMT (template), two
     // k loops in the kernel instead of eight (which spilled 300-400 registers)
     // (32-deep stages, opt-in: fp32 operands only -- the host never pairs them with split4 operands)
-    big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
-    if (A2) big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
+    // FMT == 4: both operands XPS_FMT_SPLIT4, A stored [m][k], k ranges multiples of 32: the LDS-DMA k loop (xps_gemm_dma.h)
+    if constexpr (FMT == 4) {
+        xps_big::direct_dma_pipeline<!BK>(acc, A, lda, B, ldb, m0, n0, 0, K / 32, big_smem);
+        if (A2) xps_big::direct_dma_pipeline<!BK>(acc, A2, lda, B2, ldb, m0, n0, 0, K2 / 32, big_smem);
+    } else {
+        big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A, lda, B, ldb, m0, n0, 0, K, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
+        if (A2) big_accumulate<AK, BK, DEEP, DEEP ? -1 : FMT>(acc, nocs, false, A2, lda, B2, ldb, m0, n0, 0, K2, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
+    }
     xps_big::big_store_c(acc, C, ldc, bias, m0, n0, accumulate);
 }
 
 // same A, up to 4 (B, bias, C): logical order (m-tile, problem, n-tile)
-template <bool DEEP>
+template <bool DEEP, bool DMA = false>
 __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* __restrict__ A, long long lda, NtMulti pm, long long ldb,
                                                                     long long ldc, int N, int K, int nprob, int fmt) {
     const int tiles_n = N / xps_big::TN;
@@ -617,7 +623,8 @@ __global__ __launch_bounds__(512, 1) void gemm_big_nt_multi_kernel(const float* 
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
-    big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
+    if constexpr (DMA) xps_big::direct_dma_pipeline<false>(acc, A, lda, pm.B[z], ldb, m0, n0, 0, K / 32, big_smem);     // (both operands split4)
+    else big_accumulate<true, true, DEEP>(acc, nocs, false, A, lda, pm.B[z], ldb, m0, n0, 0, K, !DEEP && (fmt & 1) != 0, !DEEP && (fmt & 2) != 0);
     xps_big::big_store_c(acc, pm.C[z], ldc, pm.bias[z], m0, n0, 0);
 }
 
@@ -848,7 +855,21 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
                 const float* A2t = A2 ? (AK ? A2 + (long long)M * ra.ld : A2 + M) : nullptr;
                 return launch_gemm<AK, BK>(At, ra, B, rb, A2t, B2, K2, C + (long long)M * rc.ld, rc, bias, Mtail, N, K, accumulate, st);
             };
-            if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0 && fmt == 0)
+            bool dma_done = false;
+            if constexpr (AK) {
+                // both operands split4, A stored [m][k], whole 32-deep stages: the LDS-DMA k loop (same bits; XPS_GEMM_DMA=0: never)
+                if (fmt == 3 && K % 32 == 0 && K2 % 32 == 0 && dma_enabled()) {
+                    constexpr int lds = xps_big::direct_dma_lds<!BK>();
+                    static const bool ready4 = big_prepare(gemm_big_kernel<AK, BK, false, 4>, lds);
+                    if (ready4) {
+                        hipLaunchKernelGGL((gemm_big_kernel<AK, BK, false, 4>), bgrid, dim3(xps_big::NTHR), lds, st,
+                                           A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
+                        dma_done = true;
+                    }
+                }
+            }
+            if (dma_done) {
+            } else if (big_deep_allowed() && K % 32 == 0 && K2 % 32 == 0 && fmt == 0)
                 hipLaunchKernelGGL((gemm_big_kernel<AK, BK, true>), bgrid, dim3(xps_big::NTHR), BIG_LDS32, st,
                                    A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
             else if (fmt == 0)
@@ -999,7 +1020,11 @@ extern "C" int xps_gemm_nt_multi_f32(const float* A, const xps_rowmap* ra_, cons
             const int Mfull = M;
             M = big_split_rows(M, (N / xps_big::TN) * nprob);
             const dim3 bgrid((M / xps_big::TM) * (N / xps_big::TN) * nprob);
-            if (big_deep_allowed() && K % 32 == 0 && fmt == 0)
+            static const bool ready_dma = big_prepare(gemm_big_nt_multi_kernel<false, true>, xps_big::direct_dma_lds<false>());
+            if (fmt == 3 && K % 32 == 0 && dma_enabled() && ready_dma)          // both operands split4: the LDS-DMA k loop (same bits)
+                hipLaunchKernelGGL((gemm_big_nt_multi_kernel<false, true>), bgrid, dim3(xps_big::NTHR), xps_big::direct_dma_lds<false>(),
+                                   (hipStream_t)stream, A, ra.ld, pm, rb.ld, rc.ld, N, K, nprob, fmt);
+            else if (big_deep_allowed() && K % 32 == 0 && fmt == 0)
                 hipLaunchKernelGGL(gemm_big_nt_multi_kernel<true>, bgrid, dim3(xps_big::NTHR), BIG_LDS32, (hipStream_t)stream, A, ra.ld, pm,
                                    rb.ld, rc.ld, N, K, nprob, fmt);
             else

@@ -269,4 +269,135 @@ __device__ inline void dma_colsum_store(const f32x16& cacc, float* __restrict__ 
     }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA k loop for the DIRECT forms (C = A B^T: NT, both operands stored [x][k]; C = A B: NN, A [x][k], B [k][x]) on
+// XPS_FMT_SPLIT4 operands, 32-deep stages.
+//
+// [x][k] operand ("KC"): a row holds its k values contiguously, 32 of them = 8 split4 groups = 128 bytes = ONE cache line.  A
+// DMA piece moves 8 rows x 128 B (full lines); the image is the 256 rows back to back (32 KB, no padding).  An MFMA fragment
+// (lane -> row, 8 consecutive k) needs the hi halves of TWO neighbouring groups: each group is read whole (ds_read_b128:
+// hi[0..3] | lo[0..3]) and the halves of the pair are regrouped in registers (the alternative, ds_read2_b64 of the hi halves
+// only, runs at half the LDS rate and cannot be made conflict-free: hi halves occupy every other 8-byte bank pair).  Bank
+// conflicts: rows are 128 B apart, so the 16 rows of a b128 lane group would share two 16-byte slots; the 16-byte group g of
+// row r therefore sits at group position g ^ ((r >> 1) & 7) -- applied on the SOURCE side (each lane of a piece fetches the
+// group that belongs at its linear LDS position: a permutation inside one cache line) and undone by the fragment addresses.
+// [k][x] operand ("KX", the B of the NN form): two 16-row images of the weight-gradient loop above (transposing reads).
+//
+// Two stages (2 x ~64 KB): stage s + 1 is in flight while stage s is multiplied; its refill is issued behind the barrier that
+// ends the multiplication.  Per accumulator the MFMAs come k-tile by k-tile (lo*hi, hi*lo, hi*hi): same bits as every other
+// tile kernel.
+constexpr int KC_IMG = 256 * 128;                                  // 32768 B
+template <bool BKX> struct DirectStage { static constexpr int B_IMG = BKX ? 2 * DMA_IMG : KC_IMG; static constexpr int BYTES = KC_IMG + B_IMG; };
+template <bool BKX> constexpr int direct_dma_lds() { return 2 * DirectStage<BKX>::BYTES; }
+
+// acc += A[m0.., kbeg .. kbeg + 32 nks) op(B)[.., n0..]; A: [m][k] split4 (lda elements per row); B: BKX ? [k][n] : [n][k], split4
+template <bool BKX>
+__device__ inline void direct_dma_pipeline(f32x16 (&acc)[4][2], const float* __restrict__ A, long long lda, const float* __restrict__ B,
+                                           long long ldb, int m0, int n0, int kbeg, int nks, unsigned char* smem) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    constexpr int STAGE = DirectStage<BKX>::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const unsigned lds0 = dma_lds_base(smem);
+    if (nks <= 0) return;
+    // ---- DMA roles.  KC image: wave w moves the pieces w, w + 8, w + 16, w + 24 (rows 8 p .. 8 p + 7): lane -> (row 8 p + lane / 8,
+    //      group (lane % 8) ^ key(row)); key = ((row >> 1) & 7) is the same for the wave's four pieces (64 rows apart)
+    const int rr = lane >> 3, cpos = lane & 7;
+    const int keyw = ((8 * wave + rr) >> 1) & 7;
+    const unsigned va = (unsigned)((long long)(8 * wave + rr) * lda * 4 + ((cpos ^ keyw) * 16));
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(A + (long long)m0 * lda + kbeg);
+    const long long pstepa = 64 * lda * 4;                          // next piece of the wave: 64 rows further
+    unsigned vb, vb1 = 0;
+    const unsigned char* bbase;
+    long long pstepb, kstepb;
+    if (BKX) {
+        // KX image: wave w moves rows 2 w, 2 w + 1 of both 16-row k-tiles
+        vb = (unsigned)((long long)(2 * wave) * ldb * 4 + lane * 16);
+        vb1 = vb + (unsigned)(ldb * 4);
+        bbase = reinterpret_cast<const unsigned char*>(B + (long long)kbeg * ldb + n0);
+        pstepb = 16 * ldb * 4;
+        kstepb = 32 * ldb * 4;
+    } else {
+        vb = (unsigned)((long long)(8 * wave + rr) * ldb * 4 + ((cpos ^ keyw) * 16));
+        bbase = reinterpret_cast<const unsigned char*>(B + (long long)n0 * ldb + kbeg);
+        pstepb = 64 * ldb * 4;
+        kstepb = 128;
+    }
+    const unsigned ra0 = (unsigned)dma_rowoff(2 * wave), ra1 = (unsigned)dma_rowoff(2 * wave + 1);
+    // piece pc (0..3: A, 4..7: B) of stage ks (beyond the range: the last stage again, into a buffer nobody reads)
+    auto piece = [&](int ks, int pc) {
+        const int kk = ks < nks ? ks : nks - 1;
+        const unsigned st = lds0 + (unsigned)(ks & 1) * STAGE;
+        if (pc < 4) dma_piece(abase + (long long)kk * 128 + pc * pstepa, va, st + (unsigned)(wave + 8 * pc) * 1024u);
+        else if (!BKX) dma_piece(bbase + (long long)kk * kstepb + (pc - 4) * pstepb, vb, st + KC_IMG + (unsigned)(wave + 8 * (pc - 4)) * 1024u);
+        else {
+            const int t = (pc - 4) >> 1;                               // k-tile of the stage; (pc & 1): row 2 w / 2 w + 1
+            dma_piece(bbase + (long long)kk * kstepb + t * pstepb, (pc & 1) ? vb1 : vb, st + KC_IMG + (unsigned)t * DMA_IMG + ((pc & 1) ? ra1 : ra0));
+        }
+    };
+    // ---- fragment addresses.  KC: lane -> row x0 + (lane & 31), k = 16 t + 8 h + 0..7 = groups 4 t + 2 h, + 1 at positions ^ key
+    const int r = lane & 31, h = lane >> 5, key = (r >> 1) & 7;
+    int fka[2][2];                                                    // [t][j]: byte offset inside the image for row group 0 of the wave
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fka[t][j] = r * 128 + (((4 * t + 2 * h + j) ^ key) << 4);
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int fro = dma_rowoff(8 * (g >> 1) + q) + ((g & 1) * 4 + pp) * 16;       // KX fragment offset (see tn_dma_pipeline)
+    auto frag_kc = [&](const unsigned char* img, int x0, int t, bf16x8& fh, bf16x8& fl) {
+        const bf16x8 ga = *reinterpret_cast<const bf16x8*>(img + x0 * 128 + fka[t][0]);
+        const bf16x8 gb = *reinterpret_cast<const bf16x8*>(img + x0 * 128 + fka[t][1]);
+        fh = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 8, 9, 10, 11);
+        fl = __builtin_shufflevector(ga, gb, 4, 5, 6, 7, 12, 13, 14, 15);
+    };
+    auto frag_kx = [&](const unsigned char* img, int x0, int t, bf16x8& fh, bf16x8& fl) {
+        const unsigned char* p = img + t * DMA_IMG + fro + (x0 / 4) * 16;
+        const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+        const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + DMA_ROW4));
+        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 8));
+        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + DMA_ROW4 + 8));
+        fh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        fl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) piece(0, pc);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) piece(1, pc);
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // this wave's pieces of stage ks have landed (stage ks + 1 in flight)
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sa = smem + (ks & 1) * STAGE;
+        const unsigned char* sb = sa + KC_IMG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (BKX) frag_kx(sb, wn + 32 * j, t, bh[j], bl[j]);
+                else frag_kc(sb, wn + 32 * j, t, bh[j], bl[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x8 ah, al;
+                frag_kc(sa, wm + 32 * i, t, ah, al);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // everybody is done reading stage ks: refill its buffer
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) piece(ks + 2, pc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace xps_big

@@ -214,6 +214,52 @@ def test_weight_gradient_lds_dma_loop_equals_register_staged_loop_bitwise(K, M, 
         assert bool(((dma_cs.double() - reg_cs.double()).abs() <= bound).all())
 
 
+@pytest.mark.parametrize('K', [32, 96, 1024])
+def test_direct_forms_lds_dma_loop_equals_register_staged_loop_bitwise(K, tiles, monkeypatch):
+    """The LDS-DMA k loop of the direct 256-tile forms (csrc/xps_gemm_dma.h: direct_dma_pipeline; XPS_FMT_SPLIT4 operands, [x][k]
+    rows moved as whole cache lines with a source-side bank swizzle, group pairs regrouped in registers; the [k][x] operand of
+    the NN form through transposing reads) against the register-staged loop (XPS_GEMM_DMA=0) and the 128-tile kernels: NT, NN,
+    the two-operand NN of the bidirectional input gradient and the multi-B projection -- bit for bit, bias and accumulate
+    epilogues included; against fp64 within the split-product bound."""
+    xf = XF()
+    g = torch.Generator().manual_seed(100 + K)
+    A = torch.randn(M0, K, generator=g).cuda()
+    A2 = torch.randn(M0, K, generator=g).cuda()
+    B = (torch.randn(N0, K, generator=g) * 0.5).cuda()                       # NT: [n][k]
+    Bt = (torch.randn(K, N0, generator=g) * 0.5).cuda()                      # NN: [k][n]
+    Bt2 = (torch.randn(K, N0, generator=g) * 0.5).cuda()
+    bias = torch.randn(N0, generator=g).cuda()
+    C0 = torch.randn(M0, N0, generator=g).cuda()
+    A4, A24, B4, Bt4, Bt24 = (xf.split4(t) for t in (A, A2, B, Bt, Bt2))
+    ra, rbk, rbn, rc = rowmap(K, fmt=1), rowmap(K, fmt=1), rowmap(N0, fmt=1), rowmap(N0)
+
+    def run():
+        c_nt = C0.clone()
+        xf.gemm_nt(A4, B4, c_nt, M0, N0, K, bias=bias, accumulate=True, ra=ra, rb=rbk)
+        c_nn = torch.empty(M0, N0, device='cuda')
+        xf.gemm_nn(A4, Bt4, c_nn, M0, N0, K, ra=ra, rb=rbn)
+        c_nn2 = torch.empty(M0, N0, device='cuda')
+        call('xps_gemm_nn2_f32', xf._ptr(A4), xf._ptr(Bt4), K, xf._ptr(A24), xf._ptr(Bt24), K, C.byref(ra), C.byref(rbn), xf._ptr(c_nn2),
+             C.byref(rc), M0, N0, 0, xf._stream())
+        cs = [torch.empty(M0, N0, device='cuda') for _ in range(2)]
+        call('xps_gemm_nt_multi_f32', xf._ptr(A4), C.byref(ra), xf._ptr_array([B4, B4]), C.byref(rbk), xf._ptr_array(cs), C.byref(rc),
+             xf._ptr_array([bias, bias]), 2, M0, N0, K, xf._stream())
+        torch.cuda.synchronize()
+        return c_nt, c_nn, c_nn2, cs[0], cs[1]
+
+    tiles(1)
+    monkeypatch.setenv('XPS_GEMM_DMA', '1'); dma = run()
+    monkeypatch.setenv('XPS_GEMM_DMA', '0'); reg = run()
+    tiles(0); small = run()
+    for a, b, c in zip(dma, reg, small):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    a64 = A.double()
+    ref_nt = a64 @ B.double().T + bias.double() + C0.double()
+    assert bool(((dma[0].double() - ref_nt).abs() <= _bound(a64, B.double().T) + 1e-5).all())
+    ref_nn2 = a64 @ Bt.double() + A2.double() @ Bt2.double()
+    assert bool(((dma[2].double() - ref_nn2).abs() <= _bound(a64, Bt.double()) + _bound(A2.double(), Bt2.double()) + 1e-5).all())
+
+
 def test_opt_in_32_deep_stages_same_bits():
     """XPS_GEMM_BIG_DEEP=1 (32-deep LDS stages with swizzled [x][k] images, read once per process): the direct forms must
     still equal the 128-tile kernels bit for bit.  Own process because the switch is read at first use."""
