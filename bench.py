@@ -158,8 +158,22 @@ def cpu_baseline(c):
                            'sample': f'{sub}-trial batch, 1 warm-up + 2 timed steps, median {med_one * 1e3:.0f} ms/step'}}
 
 
-def _event_time(fn, iters=20, warm=3):
-    """Average launch duration by HIP events on torch's current stream (= the stream the C ABI launches on)."""
+def _event_time(fn, iters=20, warm=3, prepare=None):
+    """Average launch duration by HIP events on torch's current stream (= the stream the C ABI launches on).
+    prepare: enqueued in front of EVERY timed launch and outside its event pair (e.g. the producer pass that writes the launch's
+    input, so that the launch finds its input where the training step leaves it -- partly in the Infinity Cache -- instead of
+    re-reading a buffer the previous identical launch has long pushed out)."""
+    if prepare is not None:
+        for _ in range(warm):
+            prepare(); fn()
+        pairs = []
+        for _ in range(iters):
+            prepare()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / iters * 1e-3
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -288,7 +302,12 @@ def roofline_cluster(model, c, dev):
     b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
     gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
     dy = torch.randn(Tp, B, 2 * H, device=dev) * 0.1
-    t_f = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True), iters=10)
+    # forward: gi is written by the projection GEMM right in front of the launch in the step; the probe re-writes it (an HBM-rate
+    # copy, outside the event pair) before every timed launch.  (Round 3 timed back-to-back launches on one stale 503-MB gi: 615 us
+    # against 470-510 us for the same kernel inside the profiled step -- the VERDICT's "one of the two numbers is not measuring
+    # what the step runs": it was the probe.)
+    gi_src = gi.clone()
+    t_f = _event_time(lambda: XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True), iters=10, prepare=lambda: gi.copy_(gi_src))
     y_ext, saved = XF._gru_forward(gi, w_hh, b_hh, None, Tp, B, H, 2, True)
     split = XF.split4_wanted(Tp, B, H, 2)
     t_b = _event_time(lambda: XF._gru_backward(dy, None, y_ext, saved, w_hh, Tp, B, H, 2, False, split4=split), iters=10)

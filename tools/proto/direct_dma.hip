@@ -36,7 +36,15 @@ __global__ __launch_bounds__(512, 2) void direct_kernel(const float* __restrict_
         f32x4 cs = {0.f, 0.f, 0.f, 0.f};
         big_pipeline_t<true, !BKX, true, true>(acc, cs, false, la, lb, K / 16, st);
     }
+#ifdef ABL_NOSTORE        // (timing ablation: the k loop without the C stores; the accumulators are kept alive)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+    if (threadIdx.x == 9999) big_store_c(acc, C, N, nullptr, m0, n0, 0);
+#else
     big_store_c(acc, C, N, nullptr, m0, n0, 0);
+#endif
 }
 
 static float randn() {
