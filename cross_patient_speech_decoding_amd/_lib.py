@@ -102,6 +102,7 @@ SIGNATURES = {
     'xps_decoder_select_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'xps_dropout_f32': (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _vp]),
     'xps_split4_f32': (_i, [_vp, _vp, _i64, _f, C.c_uint64, _vp]),
+    'xps_split4_pad_f32': (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp]),
     'xps_mask_scale_f32': (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     'xps_add_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'xps_cross_entropy_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),

@@ -591,12 +591,22 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(const float* __restric
                                                            long long ldb, const float* __restrict__ A2, const float* __restrict__ B2,
                                                            int K2, float* __restrict__ C, long long ldc,
                                                            const float* __restrict__ bias, int N, int K, int accumulate, int fmt) {
-    const int tiles_n = N / xps_big::TN;
+    // FMT == 5: the FMT == 4 loop on a SKINNY problem -- N < 256 columns in one 256-wide tile: B's rows are readable to 256
+    // columns (its leading dimension says so; what lies beyond column N only reaches output columns that are never stored), the
+    // waves whose 64 columns lie beyond N idle in the MFMA phase, C (leading dimension ldc) gets its N columns
+    const int tiles_n = FMT == 5 ? 1 : N / xps_big::TN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * xps_big::TM, n0 = (lid % tiles_n) * xps_big::TN;
     f32x16 acc[4][2];
     xps_big::big_zero(acc);
     f32x4 nocs = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FMT == 5) {
+        const bool act = (int)((threadIdx.x >> 6) & 3) * 64 < N;
+        xps_big::direct_dma_pipeline<!BK>(acc, A, lda, B, ldb, m0, 0, 0, K / 32, big_smem, act);
+        if (A2) xps_big::direct_dma_pipeline<!BK>(acc, A2, lda, B2, ldb, m0, 0, 0, K2 / 32, big_smem, act);
+        xps_big::big_store_c_masked(acc, C, ldc, bias, m0, N, accumulate);
+        return;
+    }
     // fmt: bit 0 = A (and A2), bit 1 = B (and B2) are XPS_FMT_SPLIT4 operands; 16-deep stages: fmt == FMT (template), two
     // k loops in the kernel instead of eight (which spilled 300-400 registers)
     // (32-deep stages, opt-in: fp32 operands only -- the host never pairs them with split4 operands)
@@ -835,6 +845,21 @@ int launch_gemm(const float* A, const RowMap& ra, const float* B, const RowMap& 
         hipLaunchKernelGGL((gemm_small_kernel<AK, BK>), dim3(cdiv(N, 64)), dim3(1024), 0, st, A, ra, B, rb, A2, B2, K2, C, rc,
                            bias, M, N, K, accumulate, vecB);
         return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if constexpr (AK && !BK) {
+        // skinny input gradient (configs[3] layer 0: 40960 x 100 x 3072, HBM-bound on A): ONE 256-wide tile per 256 rows on the
+        // LDS-DMA loop; needs B's rows readable (and split4) to 256 columns: the caller hands a zero-padded image (rb.ld >= 256)
+        if (big_enabled() && dma_enabled() && fmt == 3 && N < xps_big::TN && N % 4 == 0 && rb.ld >= xps_big::TN && M % xps_big::TM == 0 &&
+            M / xps_big::TM >= 96 && K % 32 == 0 && K2 % 32 == 0 && K + K2 >= 512 && big_plain(A, ra, M) && big_plain(B, rb, K) &&
+            (!A2 || (big_plain(A2, ra, M) && big_plain(B2, rb, K2))) && rc.rpg >= M) {
+            constexpr int lds = xps_big::direct_dma_lds<true>();
+            static const bool ready5 = big_prepare(gemm_big_kernel<true, false, false, 5>, lds);
+            if (ready5) {
+                hipLaunchKernelGGL((gemm_big_kernel<true, false, false, 5>), dim3(M / xps_big::TM), dim3(xps_big::NTHR), lds, st,
+                                   A, ra.ld, B, rb.ld, A2, B2, K2, C, rc.ld, bias, N, K, accumulate, fmt);
+                return hipGetLastError() == hipSuccess ? 0 : -1;
+            }
+        }
     }
     if (big_enabled() && M % xps_big::TM == 0 && N % xps_big::TN == 0 && K % BKT == 0 && K2 % BKT == 0 && K >= 64 &&
         (long long)(M / xps_big::TM) * (N / xps_big::TN) >= big_min_tiles() &&

@@ -342,6 +342,32 @@ __device__ inline void big_store_c(const f32x16 (&acc)[4][2], float* __restrict_
         }
 }
 
+// the same for a tile whose columns >= nvalid do not exist (a skinny problem, N < 256, in ONE 256-wide tile: C has N columns)
+__device__ inline void big_store_c_masked(const f32x16 (&acc)[4][2], float* __restrict__ C, long long ldc, const float* __restrict__ bias,
+                                          int m0, int nvalid, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int li = lane & 31, lk = lane >> 5;
+    if (wn >= nvalid) return;
+    float* cbase = C + (long long)(m0 + wm + 4 * lk) * ldc + wn + li;
+    const bool ok[2] = {wn + li < nvalid, wn + 32 + li < nvalid};
+    float bv[2] = {0.f, 0.f};
+    if (bias) { bv[0] = ok[0] ? bias[wn + li] : 0.f; bv[1] = ok[1] ? bias[wn + 32 + li] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* crow = cbase + (long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!ok[j]) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (accumulate) v += crow[j * 32];
+                __builtin_nontemporal_store(v, &crow[j * 32]);
+            }
+        }
+}
+
 // Split-K slab of a 256 x 256 tile, written as its four 128 x 128 sub-tiles in the register order of the small-tile
 // kernels (xps_gemm.hip: slab_store / slab_decode), so that ONE reduce kernel serves both tile shapes: sub-tile
 // (wave / 4, (wave % 4) / 2), its "wave" = 2 (i / 2) + wave % 2, its accumulator tile (i % 2, j).

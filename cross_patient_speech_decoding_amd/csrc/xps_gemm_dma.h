@@ -295,7 +295,9 @@ template <bool BKX> constexpr int direct_dma_lds() { return 2 * DirectStage<BKX>
 // acc += A[m0.., kbeg .. kbeg + 32 nks) op(B)[.., n0..]; A: [m][k] split4 (lda elements per row); B: BKX ? [k][n] : [n][k], split4
 template <bool BKX>
 __device__ inline void direct_dma_pipeline(f32x16 (&acc)[4][2], const float* __restrict__ A, long long lda, const float* __restrict__ B,
-                                           long long ldb, int m0, int n0, int kbeg, int nks, unsigned char* smem) {
+                                           long long ldb, int m0, int n0, int kbeg, int nks, unsigned char* smem, const bool active = true) {
+    // active (wave-uniform): false = this wave's 64 output columns are beyond the problem (skinny N in a 256-wide tile): it moves
+    // its DMA pieces and keeps the barriers, but reads no fragments and issues no MFMAs
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     constexpr int STAGE = DirectStage<BKX>::BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -371,6 +373,7 @@ __device__ inline void direct_dma_pipeline(f32x16 (&acc)[4][2], const float* __r
         __builtin_amdgcn_s_barrier();
         const unsigned char* sa = smem + (ks & 1) * STAGE;
         const unsigned char* sb = sa + KC_IMG;
+        if (active)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 bh[2], bl[2];

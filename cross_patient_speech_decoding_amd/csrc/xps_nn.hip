@@ -784,6 +784,30 @@ extern "C" int xps_split4_f32(const float* x, float* out, int64_t n, float drop_
     return XPS_OK;
 }
 
+namespace {
+// out[r][0 .. ldo) = the XPS_FMT_SPLIT4 image of x[r][0 .. cols), zero beyond (cols, ldo multiples of 4)
+__global__ __launch_bounds__(256) void split4_pad_kernel(const float* __restrict__ x, long long ldx, int rows, int cols, float* __restrict__ out,
+                                                         long long ldo) {
+    const long long g4 = ldo / 4, idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows * g4) return;
+    const long long r = idx / g4;
+    const int c = (int)(idx % g4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) v = split4_pack(*reinterpret_cast<const f32x4*>(x + r * ldx + c));
+    *reinterpret_cast<f32x4*>(out + r * ldo + c) = v;
+}
+}  // namespace
+
+extern "C" int xps_split4_pad_f32(const float* x, int64_t ldx, int rows, int cols, float* out, int64_t ldo, void* stream) {
+    XPS_CHECK_ARG(x && out && rows >= 0 && cols >= 0 && cols % 4 == 0 && ldo % 4 == 0 && ldo >= cols && ldx % 4 == 0 && ldx >= cols, "bad argument");
+    XPS_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "buffers must be 16-byte aligned");
+    if (rows == 0 || ldo == 0) return XPS_OK;
+    hipLaunchKernelGGL(split4_pad_kernel, dim3(cdiv((long long)rows * (ldo / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, rows,
+                       cols, out, (long long)ldo);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
+
 extern "C" int xps_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
     XPS_CHECK_ARG(a && b && out && n >= 0, "bad argument");
     if (n == 0) return XPS_OK;

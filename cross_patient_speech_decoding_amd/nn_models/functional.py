@@ -519,6 +519,24 @@ def _presplit_weights_ok(rows, In, H3):
             and os.environ.get('XPS_SPLIT4_WEIGHTS', '1') != '0')
 
 
+def skinny_dx_wanted(rows, In, K):
+    """OPT-IN (XPS_SKINNY_DX=1): the input gradient of a large layer with few input channels on the LDS-DMA loop through a
+    zero-padded weight image (xps_split4_pad_f32).  Measured on configs[3] layer 0 (40960 x 100 x 3072, round 4, rocprofv3):
+    261 us against 213 us for the 64-row edge tiles -- one 256-row tile per CU streams its 3 MB of dgi AND 3 MB of padded
+    weight rows through the same ~25 GB/s per-CU LDS ingest, on 160 of 256 CUs; the edge tiles re-use the weight tile from L1 /
+    L2 three blocks per CU.  Same bits either way (tests/test_gpu_gemm_big.py); not the default."""
+    return (os.environ.get('XPS_SKINNY_DX', '0') == '1' and split4_mode() and In % 4 == 0 and In < 256 and rows % 256 == 0
+            and rows >= 96 * 256 and K % 32 == 0 and K >= 512 and os.environ.get('XPS_GEMM_DMA', '1') != '0')
+
+
+def split4_pad(w, ldo):
+    """XPS_FMT_SPLIT4 image of the 2-D matrix w with leading dimension ldo (zero beyond w's columns)."""
+    w = w.contiguous()
+    out = torch.empty(w.shape[0], ldo, dtype=_f32, device=w.device)
+    call('xps_split4_pad_f32', _ptr(w), w.shape[1], w.shape[0], w.shape[1], _ptr(out), ldo, _stream())
+    return out
+
+
 def split4(x, drop_p=0.0, seed=0):
     """XPS_FMT_SPLIT4 image of dropout(x) (drop_p = 0: of x): a GEMM input operand for rowmap(..., fmt=1), not fp32 values."""
     out = torch.empty_like(x)
@@ -641,12 +659,20 @@ class GRULayerFmtFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, In, dtype=_f32, device=dev)
+            if fmt and not w_fmt and skinny_dx_wanted(T * B, In, 3 * H):
+                # few input channels (configs[3] layer 0: In = 100): dx = dgi W_ih is bound by the read of dgi (503 MB), not by the
+                # matrix pipe -- W_ih as a zero-padded 256-column split4 image, so that the product takes ONE 256-wide tile per 256
+                # rows on the LDS-DMA loop (gemm_big_kernel<.., 5>: 213 -> ~120 us) instead of 64-row edge tiles
+                w_ih = [split4_pad(w, 256) for w in w_ih]
+                w_fmt, ldw = 1, 256
+            else:
+                ldw = In
             if ndir == 2:       # both directions summed in registers: one launch, no accumulate pass over dx
-                ra, rb, rc = rowmap(3 * H, fmt=fmt), rowmap(In, fmt=w_fmt), rowmap(In)
+                ra, rb, rc = rowmap(3 * H, fmt=fmt), rowmap(ldw, fmt=w_fmt), rowmap(In)
                 call('xps_gemm_nn2_f32', _ptr(dgi[0]), _ptr(w_ih[0]), 3 * H, _ptr(dgi[1]), _ptr(w_ih[1]), 3 * H,
                      C.byref(ra), C.byref(rb), _ptr(dx), C.byref(rc), T * B, In, 0, _stream())
             else:
-                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(In, fmt=w_fmt))
+                gemm_nn(dgi[0], w_ih[0], dx, T * B, In, 3 * H, ra=rowmap(3 * H, fmt=fmt), rb=rowmap(ldw, fmt=w_fmt))
         grads = []
         for d in range(ndir):
             grads += [rets_ih[d][0], rets_hh[d][0], rets_ih[d][1], rets_hh[d][1]]

@@ -313,6 +313,10 @@ int xps_dropout_f32(const float* x, float* out, float* mask, int64_t n, float p,
  * GEMMs read (a layer input that exists only as the dropped output of the previous layer, weights once per forward pass):
  * the tile kernels then stage them without conversion arithmetic.  n % 4 == 0, 16-byte aligned buffers. */
 int xps_split4_f32(const float* x, float* out, int64_t n, float drop_p, uint64_t seed, void* stream);
+/* XPS_FMT_SPLIT4 image of a rows x cols fp32 matrix (leading dimension ldx) written with leading dimension ldo >= cols and ZERO
+ * beyond column cols: a [k][n] GEMM operand whose rows are readable to a full 256-column tile (the skinny input-gradient product
+ * of a layer with few input channels -- configs[3] layer 0: dx = dgi W_ih with In = 100 -- takes the LDS-DMA loop that way) */
+int xps_split4_pad_f32(const float* x, int64_t ldx, int rows, int cols, float* out, int64_t ldo, void* stream);
 /* out = x * mask * scale */
 int xps_mask_scale_f32(const float* x, const float* mask, float scale, float* out, int64_t n, void* stream);
 /* out = a + b (elementwise) */

@@ -260,6 +260,43 @@ def test_direct_forms_lds_dma_loop_equals_register_staged_loop_bitwise(K, tiles,
     assert bool(((dma[2].double() - ref_nn2).abs() <= _bound(a64, Bt.double()) + _bound(A2.double(), Bt2.double()) + 1e-5).all())
 
 
+@pytest.mark.parametrize('N', [100, 64, 200])
+def test_skinny_input_gradient_on_the_lds_dma_loop_equals_edge_tiles_bitwise(N, tiles, monkeypatch):
+    """configs[3] layer 0: dx = dgi_fwd W_fwd + dgi_bwd W_bwd with In = 100 input channels (40960 x 100 x 2 * 1536; here 24576 rows).
+    The product is bound by the read of dgi: with W handed over as a zero-padded 256-column split4 image (xps_split4_pad_f32) it
+    runs ONE 256-wide tile per 256 rows on the LDS-DMA loop (gemm_big_kernel<.., 5>: waves beyond column N idle, masked C
+    store) -- bit for bit what the 64-row edge tiles give on the unpadded operands, within the split-product bound of fp64."""
+    xf = XF()
+    g = torch.Generator().manual_seed(N)
+    M, K = 96 * 256, 1536
+    A1 = (torch.randn(M, K, generator=g) * 0.1).cuda()
+    A2 = (torch.randn(M, K, generator=g) * 0.1).cuda()
+    W1 = (torch.randn(K, N, generator=g) * 0.3).cuda()
+    W2 = (torch.randn(K, N, generator=g) * 0.3).cuda()
+    A14, A24 = xf.split4(A1), xf.split4(A2)
+    ra, rc = rowmap(K, fmt=1), rowmap(N)
+
+    def nn2(b1, b2, rb):
+        out = torch.full((M, N), 7.0, device='cuda')
+        call('xps_gemm_nn2_f32', xf._ptr(A14), xf._ptr(b1), K, xf._ptr(A24), xf._ptr(b2), K, C.byref(ra), C.byref(rb), xf._ptr(out),
+             C.byref(rc), M, N, 0, xf._stream())
+        torch.cuda.synchronize()
+        return out
+
+    tiles(1)
+    monkeypatch.setenv('XPS_GEMM_DMA', '1')
+    P1, P2 = xf.split4_pad(W1, 256), xf.split4_pad(W2, 256)
+    assert P1.shape == (K, 256) and float(P1[:, N:].abs().max()) == 0.0
+    dma = nn2(P1, P2, rowmap(256, fmt=1))
+    edge = nn2(xf.split4(W1), xf.split4(W2), rowmap(N, fmt=1))
+    plain = nn2(W1, W2, rowmap(N))
+    assert torch.equal(dma, edge) and torch.equal(dma, plain)
+    ref = A1.double() @ W1.double() + A2.double() @ W2.double()
+    assert bool(((dma.double() - ref).abs() <= _bound(A1.double(), W1.double()) + _bound(A2.double(), W2.double()) + 1e-5).all())
+    monkeypatch.setenv('XPS_SKINNY_DX', '1')                                   # (opt-in: measured slower than the edge tiles)
+    assert xf.skinny_dx_wanted(40960, 100, 1536) and not xf.skinny_dx_wanted(40960, 1024, 1536)
+
+
 def test_opt_in_32_deep_stages_same_bits():
     """XPS_GEMM_BIG_DEEP=1 (32-deep LDS stages with swizzled [x][k] images, read once per process): the direct forms must
     still equal the 128-tile kernels bit for bit.  Own process because the switch is read at first use."""
