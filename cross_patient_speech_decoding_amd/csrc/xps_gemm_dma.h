@@ -364,13 +364,71 @@ __device__ inline void direct_dma_pipeline(f32x16 (&acc)[4][2], const float* __r
         fh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
         fl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+#ifndef XPS_DIRECT_MERGED
+#define XPS_DIRECT_MERGED 0
+#endif
+#if XPS_DIRECT_MERGED
+    // (Built and measured, not the default: NT 40960-row projection shape 299.5 / 303.0 us against 299.2 / 299.5 us for the
+    //  two-barrier form below, NN 279.9 / 279.7 against 283.1 / 286.5 us -- profiles/round4: the compiler already rotates the
+    //  two-barrier loop so that the refill burst sits among the last MFMAs of a stage, and the refill keeps a whole stage of lead.)
+    // ONE barrier per stage: "every piece of stage ks has landed" and "everybody is done reading stage ks - 1" are the same
+    // barrier when the refill of the freed buffer (stage ks + 1) is issued BEHIND it, spread over the MFMA groups of the first
+    // k-tile (two pieces per row group) -- stamps of the first form (refill of stage ks + 2 in one burst behind a second barrier):
+    // per 32-deep stage and wave 44 cycles waiting for data, 1199 in the two barriers, 697 issuing the burst with an idle matrix
+    // pipe, 2974 in reads + MFMAs (3072 is the floor per SIMD).
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) piece(0, pc);
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of stage ks (the only ones in flight) have landed
+        __builtin_amdgcn_s_barrier();                              // ... everybody's; and everybody is done reading stage ks - 1
+        const unsigned char* sa = smem + (ks & 1) * STAGE;
+        const unsigned char* sb = sa + KC_IMG;
+        const bool more = ks + 1 < nks;                            // (no refill behind the last stage: nothing may land after the hand-back)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 bh[2], bl[2];
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (BKX) frag_kx(sb, wn + 32 * j, t, bh[j], bl[j]);
+                    else frag_kc(sb, wn + 32 * j, t, bh[j], bl[j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (active) {
+                    bf16x8 ah, al;
+                    frag_kc(sa, wm + 32 * i, t, ah, al);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                if (t == 0 && more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(ks + 1, 2 * i); piece(ks + 1, 2 * i + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#else
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) piece(0, pc);
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) piece(1, pc);
+#ifdef XPS_DMA_STAMP
+    unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, z_wait = 0, z_bar = 0, z_mma = 0, z_bar2 = 0, z_dma = 0;
+#endif
     for (int ks = 0; ks < nks; ++ks) {
+        DSTAMP(u0)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // this wave's pieces of stage ks have landed (stage ks + 1 in flight)
+        DSTAMP(u1)
         __builtin_amdgcn_s_barrier();
+        DSTAMP(u2)
         const unsigned char* sa = smem + (ks & 1) * STAGE;
         const unsigned char* sb = sa + KC_IMG;
         if (active)
@@ -395,10 +453,23 @@ __device__ inline void direct_dma_pipeline(f32x16 (&acc)[4][2], const float* __r
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DSTAMP(u3)
         __builtin_amdgcn_s_barrier();                               // everybody is done reading stage ks: refill its buffer
+        DSTAMP(u4)
 #pragma unroll
         for (int pc = 0; pc < 8; ++pc) piece(ks + 2, pc);
+#ifdef XPS_DMA_STAMP
+        DSTAMP(u5)
+        z_wait += u1 - u0; z_bar += u2 - u1; z_mma += u3 - u2; z_bar2 += u4 - u3; z_dma += u5 - u4;
+#endif
     }
+#ifdef XPS_DMA_STAMP
+    if (lane == 0) {
+        unsigned long long* o = g_dma_stamp + ((blockIdx.x * 8 + wave) & 4095) * 4;
+        o[0] = z_wait; o[1] = z_bar + z_bar2; o[2] = z_dma; o[3] = z_mma;
+    }
+#endif
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }

@@ -107,6 +107,18 @@ static int test(int M, int N, int K) {
     printf("  register-staged split4: %8.1f us  %6.1f TF  issued frac %.3f\n", t0, flop / t0 / 1e6, 3 * flop / t0 / 1e6 / 2500e0);
     printf("  LDS-DMA               : %8.1f us  %6.1f TF  issued frac %.3f\n", t1, flop / t1 / 1e6, 3 * flop / t1 / 1e6 / 2500e0);
     printf("  bitwise: %zu of %zu elements differ (max |d| %.3e); error vs fp64 / sum|ab|: %.3e (bound 1.6e-5)\n", diff, cn, maxd, worst);
+#ifdef XPS_DMA_STAMP
+    {
+        std::vector<unsigned long long> st(4096 * 4);
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_dma_stamp), st.size() * 8);
+        const int nw = 4096;
+        double sum[4] = {0, 0, 0, 0};
+        for (int w = 0; w < nw; ++w) for (int j = 0; j < 4; ++j) sum[j] += (double)st[w * 4 + j];
+        const double nk = (double)(K / 32) * nw;
+        printf("  stamps, cycles per 32-deep stage and wave: vmcnt wait %.0f, two barriers %.0f, DMA issue (8 pieces) %.0f, reads + 48 MFMAs %.0f (floor 1536 per wave, 3072 per SIMD)\n",
+               sum[0] / nk, sum[1] / nk, sum[2] / nk, sum[3] / nk);
+    }
+#endif
     hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
     return (diff || worst > 1.6e-5) ? 3 : 0;
 }
