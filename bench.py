@@ -484,7 +484,7 @@ def alignment_record(dev):
         a0 = a0.reshape(-1, a0.shape[-1])
         return LA.xcov(a0, Zc, mean[:128].contiguous(), mean)
     t_share = med(rank_share, n=3)
-    G = torch.cat([LA.xcov(avgs_all[i], Zc, mean[128 * i:128 * (i + 1)].contiguous(), mean) for i in range(P)], dim=0).cpu().numpy()
+    G = torch.cat([LA.xcov(avgs_all[i], Zc, mean[128 * i:128 * (i + 1)].contiguous(), mean) for i in range(P)], dim=0).contiguous()
     offs = np.arange(P + 1) * 128
     t_tail = med(lambda: _gevp(G, offs, 30, 0.5), n=3)
     by = Xd[0].numel() * 4

@@ -124,6 +124,8 @@ SIGNATURES = {
     'xps_jacobi_f64_workspace': (_sz, [_i]),
     'xps_jacobi_sweeps_f64': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'xps_jacobi_small_supported': (_i, [_i, _i, _i]),
+    'xps_chol_whiten_supported': (_i, [_i]),
+    'xps_chol_whiten_f64': (_i, [_vp, _i64, _i64, _d, _d, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp]),
     'xps_jacobi_small_f64': (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     'xps_apply_f64': (_i, [_vp, _i, _i64, _vp, _vp, _i64, _vp, _i, _i64, _i64, _i, _i, _vp]),
     'xps_process_hg_f64_workspace': (_sz, [_i, _i, _i]),

@@ -8,11 +8,14 @@ implements the published regularised SUMCOR-MCCA generalised eigenproblem on the
   G   = Zc^T Zc                 centred Gram of the concatenated views    xps_xcov_f64 (f64 MFMA)
   R_b = (1 - r) G_bb + r I      per-view regularised covariance
   LHS = G with diagonal blocks R_b ;  RHS = blockdiag(R_b)
-  R_b = V L V^T  ->  S = blockdiag(V L^-1/2 V^T)                          xps_jacobi_* per view
-  C   = S LHS S ,  top-k eigenpairs of C (Gershgorin shift + Jacobi)      xps_jacobi_*
+  R_b = L L^T    ->  S = blockdiag(L^-T)   (regs > 0)                     xps_chol_whiten_f64, all views in one launch
+  R_b = V L V^T  ->  S = blockdiag(V L^-1/2 V^T)  (regs None / 0: pseudo-inverse of a singular block)   xps_jacobi_* per view
+  C   = S^T LHS S ,  top-k eigenpairs of C (Chebyshev-filtered subspace iteration)   xps_cheb_filter_f64 / xps_jacobi_*
   loadings = rows of S V_k per view; sign rule on the normalised common scores
   transform_view(X, i) = (X - mean_i) @ loadings_i                        xps_apply_f64
 """
+import os
+
 import numpy as np
 
 from . import _linalg as LA
@@ -53,8 +56,8 @@ class DeviceMCCA:
         rows = self.own_block_rows(Vd, Z, mean, offs, world, rank)
         if world > 1:
             rows = [_bcast_matrix(rows[i], i % world, group) for i in range(P)]
-        G = LA.torch.cat(rows, dim=0).cpu().numpy()           # (D, D)
-        self.gram_ = G                                        # centred Gram of the concatenated views (before any rank reduction)
+        Gd = LA.torch.cat(rows, dim=0).contiguous()           # (D, D), stays on the device for the eigensolve
+        self._gram_d = Gd                                     # centred Gram of the concatenated views (before any rank reduction)
         self.block_rows_computed_ = [i for i in range(P) if i % world == rank]
         self.means_ = [mean[offs[i]:offs[i + 1]].cpu().numpy() for i in range(len(Vd))]
         self._means_d = [mean[offs[i]:offs[i + 1]].contiguous() for i in range(len(Vd))]
@@ -63,13 +66,13 @@ class DeviceMCCA:
             # per-view rank-k PCA basis = top eigenvectors of G_bb; the problem is solved on the scores
             bases = []
             for i, r in enumerate(self.signal_ranks):
-                _, Vb = LA.eigh_psd(LA.to_device(G[offs[i]:offs[i + 1], offs[i]:offs[i + 1]]))
+                _, Vb = LA.eigh_psd(Gd[int(offs[i]):int(offs[i + 1]), int(offs[i]):int(offs[i + 1])].contiguous())
                 bases.append(Vb[:, :max(int(r), 1)])
-            Bm = _block_diag(bases)
-            G = LA.dgemm(LA.dgemm(LA.to_device(Bm), LA.to_device(G), ta=True), LA.to_device(Bm)).cpu().numpy()
+            Bm = LA.to_device(_block_diag(bases))
+            Gd = LA.dgemm(LA.dgemm(Bm, Gd, ta=True), Bm)
             dims = [b.shape[1] for b in bases]
             offs = np.concatenate([[0], np.cumsum(dims)])
-        load_red, self.evals_ = _gevp(G, offs, self.n_components, self.regs)
+        load_red, self.evals_ = _gevp(Gd, offs, self.n_components, self.regs)
         if bases is not None:
             load_red = [LA.dgemm(LA.to_device(b), LA.to_device(l)).cpu().numpy() for b, l in zip(bases, load_red)]
         # sign rule: entry of largest magnitude of each normalised common-score column is positive
@@ -83,6 +86,11 @@ class DeviceMCCA:
         self._load_d = [LA.to_device(np.ascontiguousarray(l)) for l in self.loadings_]
         self.n_views_ = len(Vd)
         return self
+
+    @property
+    def gram_(self):
+        """The centred Gram matrix of the concatenated views as a host array (copied from the device on demand)."""
+        return self._gram_d.cpu().numpy()
 
     @staticmethod
     def own_block_rows(Vd, Z, mean, offs, world, rank):
@@ -133,35 +141,47 @@ def _bcast_matrix(t, owner, group):
     return t
 
 
-def _gevp(G, offs, n_components, regs):
-    """Top generalised eigenpairs of (LHS, RHS) built from the Gram matrix G (host ndarray, D x D);
-    the decompositions run on the device.  Returns per-view loadings and the eigenvalues."""
+def _gevp(Gd, offs, n_components, regs):
+    """Top generalised eigenpairs of (LHS, RHS) built from the Gram matrix Gd (DEVICE tensor, D x D); every matrix of size
+    D stays on the device (round 4: the 8-MB Gram / LHS / S matrices used to cross PCIe four times through pageable host memory:
+    3-30 ms of an 8-view fit, varying from call to call); the host sees the small per-view spectra and the k eigenpairs only.
+    Returns per-view loadings (host, float64) and the eigenvalues."""
+    torch = LA.torch
     P = len(offs) - 1
-    D = G.shape[0]
-    LHS = G.copy()
-    S = np.zeros_like(G)
-    blocks = []
-    for b in range(P):
-        sl = slice(offs[b], offs[b + 1])
-        Rb = G[sl, sl] if regs is None else (1.0 - regs) * G[sl, sl] + regs * np.eye(offs[b + 1] - offs[b])
-        LHS[sl, sl] = Rb
-        blocks.append(Rb)
-    # all diagonal blocks in one launch when they have one size
-    eigs = LA.eigh_psd_batched(blocks)
-    for b, (w, V) in enumerate(eigs):
-        sl = slice(offs[b], offs[b + 1])
-        keep = w > w[0] * max(blocks[b].shape[0], 1) * LA.EPS   # guards a singular unregularised block
-        Vk = V[:, keep] / np.sqrt(w[keep])
-        S[sl, sl] = LA.dgemm(LA.to_device(Vk), LA.to_device(V[:, keep]), tb=True).cpu().numpy()   # R_b^-1/2
-    Sd = LA.to_device(S)
-    Cm = LA.dgemm(LA.dgemm(Sd, LA.to_device(LHS)), Sd)
+    D = Gd.shape[0]
+    LHS = Gd.clone()
+    S = None
+    if regs and os.environ.get('XPS_MCCA_WHITEN', 'chol') != 'eig':
+        # regularised blocks R_b = (1 - r) G_bb + r I are positive definite with condition <= (lambda_max + r) / r: whitened by
+        # their Cholesky factors, S = blockdiag(L_b^-T), in ONE launch (the symmetric R_b^-1/2 from eight 128 x 128 Jacobi
+        # eigendecompositions was 5 of the 17.5 ms of this function; the eigenvectors S u of the pencil are the same)
+        S = LA.chol_whiten_blocks(Gd, offs, 1.0 - regs, regs, LHS)
+    if S is None:
+        S = torch.zeros_like(Gd)
+        blocks = []
+        for b in range(P):
+            sl = slice(int(offs[b]), int(offs[b + 1]))
+            Rb = Gd[sl, sl].contiguous()
+            if regs is not None:
+                Rb = Rb.mul(1.0 - regs)
+                Rb.diagonal().add_(regs)
+            LHS[sl, sl] = Rb
+            blocks.append(Rb)
+        # all diagonal blocks in one launch when they have one size
+        eigs = LA.eigh_psd_batched(blocks)
+        for b, (w, V) in enumerate(eigs):
+            sl = slice(int(offs[b]), int(offs[b + 1]))
+            keep = w > w[0] * max(blocks[b].shape[0], 1) * LA.EPS   # guards a singular unregularised block
+            Vk = V[:, keep] / np.sqrt(w[keep])
+            S[sl, sl] = LA.dgemm(LA.to_device(Vk), LA.to_device(V[:, keep]), tb=True)       # R_b^-1/2 (symmetric)
+    Cm = LA.dgemm(LA.dgemm(S, LHS, ta=True), S)                 # S^T LHS S
     Cm = 0.5 * (Cm + Cm.t())
     k = min(n_components, D)
     # Cm = S G S + blockdiag(I - R_b^-1/2 G_bb R_b^-1/2) is indefinite once regs > 0 (eigenvalues down to
     # -regs / (1 - regs)): eigh_sym_top shifts it positive definite before the (sign-blind) one-sided Jacobi
     w, Vc = LA.eigh_sym_top(Cm, k)
-    Vg = LA.dgemm(Sd, LA.to_device(np.ascontiguousarray(Vc))).cpu().numpy()      # RHS-orthonormal
-    return [Vg[offs[b]:offs[b + 1]] for b in range(P)], w
+    Vg = LA.dgemm(S, LA.to_device(np.ascontiguousarray(Vc))).cpu().numpy()      # RHS-orthonormal
+    return [Vg[int(offs[b]):int(offs[b + 1])] for b in range(P)], w
 
 
 class AlignMCCA:

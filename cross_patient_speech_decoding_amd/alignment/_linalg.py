@@ -202,6 +202,31 @@ def jacobi_batched(Wb, want_v=True, max_sweeps=40, tol=None):
     return Vb
 
 
+def chol_whiten_blocks(Gd, offs, scale, shift, LHS=None):
+    """Upper-triangular whitening factors S_b = L_b^-T of the diagonal blocks A_b = scale * G_bb + shift * I = L_b L_b^T of the
+    device matrix Gd (D x D), written into a block-diagonal D x D device matrix S (S^T blockdiag(A_b) S = I); A_b is also written
+    over the diagonal blocks of ``LHS`` when given.  One launch when the blocks have one size.  Returns S, or None when a block is
+    too large for the LDS-resident kernel or is not positive definite (the caller then takes the eigendecomposition route)."""
+    D = Gd.shape[0]
+    sizes = [int(offs[b + 1] - offs[b]) for b in range(len(offs) - 1)]
+    if not all(lib().xps_chol_whiten_supported(n) for n in sizes):
+        return None
+    S = torch.zeros_like(Gd)
+    info = torch.zeros(len(sizes), dtype=torch.int32, device=Gd.device)
+    ld = Gd.stride(0)
+    groups = [(0, len(sizes))] if len(set(sizes)) == 1 else [(b, 1) for b in range(len(sizes))]
+    for b0, cnt in groups:
+        n, o = sizes[b0], int(offs[b0])
+        step = n * (ld + 1) * 8
+        call('xps_chol_whiten_f64', Gd.data_ptr() + o * (ld + 1) * 8, ld, n * (ld + 1), float(scale), float(shift),
+             None if LHS is None else LHS.data_ptr() + o * (LHS.stride(0) + 1) * 8, 0 if LHS is None else LHS.stride(0),
+             0 if LHS is None else n * (LHS.stride(0) + 1), S.data_ptr() + o * (S.stride(0) + 1) * 8, S.stride(0),
+             n * (S.stride(0) + 1), n, cnt, info.data_ptr() + 4 * b0, _stream())
+    if int(info.abs().max().item()) != 0:
+        return None
+    return S
+
+
 def svd(A):
     """Thin SVD of a small float64 device matrix by one-sided Jacobi: A = U diag(s) Vt, s descending.
     Returns numpy (U, s, Vt)."""

@@ -868,7 +868,114 @@ int jacobi_small_vmode(int m, int n, int want_v) {
     if (!want_v) return 0;
     return (w + (long long)n * (n | 1) <= JS_LDS_DOUBLES) ? 1 : 2;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Whitening factor of a batch of small symmetric positive definite blocks (the regularised within-view covariances R_b of
+// the MCCA eigenproblem, AlignMCCA._gevp): A = scale * R + shift * I = L L^T (right-looking Cholesky), S = L^-T (upper
+// triangular), so that S^T A S = I.  One workgroup per block, A in LDS (rows padded to an odd length); the inverse is found
+// column by column (thread c solves L x = e_c; the loops over (i, k) are uniform, so L[i][k] is one broadcast read and
+// x_c[k] -- kept in the unused upper triangle -- a conflict-free one).  info[b] = 0, or j + 1 when pivot j is not positive.
+constexpr int CW_THREADS = 256, CW_MAX_N = 136;
+__global__ __launch_bounds__(CW_THREADS) void chol_whiten_kernel(const double* __restrict__ Rg, long long ldr, long long sr,
+                                                                 double scale, double shift, double* __restrict__ Ag,
+                                                                 long long lda, long long sa, double* __restrict__ Sg,
+                                                                 long long ldsg, long long ss, int n, int* __restrict__ info) {
+    extern __shared__ double cw[];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, ld = n | 1;
+    double* A = cw;                       // n x ld
+    double* dinv = cw + (size_t)n * ld;   // 1 / L[j][j]
+    Rg += (long long)blockIdx.x * sr;
+    Sg += (long long)blockIdx.x * ss;
+    if (Ag) Ag += (long long)blockIdx.x * sa;
+    if (tid == 0) s_bad = 0;
+    for (int idx = tid; idx < n * n; idx += CW_THREADS) {
+        const int i = idx / n, j = idx - i * n;
+        // the block is symmetric up to rounding of its two GEMM halves: the LOWER triangle is the one factorised
+        double v = scale * Rg[(long long)i * ldr + j] + (i == j ? shift : 0.0);
+        A[i * ld + j] = v;
+        if (Ag) Ag[(long long)i * lda + j] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double d = A[j * ld + j];
+        if (!(d > 0.0) || !(d < 1.7e308)) {              // uniform: every thread reads the same pivot
+            if (tid == 0) { s_bad = j + 1; }
+            break;
+        }
+        const double r = 1.0 / sqrt(d);
+        __syncthreads();                                  // pivot read by all before column j is scaled
+        for (int i = j + 1 + tid; i < n; i += CW_THREADS) A[i * ld + j] *= r;
+        if (tid == 0) { A[j * ld + j] = sqrt(d); dinv[j] = r; }
+        __syncthreads();
+        // trailing update of the lower triangle: A[i][k] -= L[i][j] * L[k][j], j < k <= i
+        const int rem = n - 1 - j;
+        const int cnt = rem * (rem + 1) / 2;
+        for (int t = tid; t < cnt; t += CW_THREADS) {
+            // t -> (a, b), 0 <= b <= a < rem (row-wise enumeration of the triangle)
+            int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((a + 1) * (a + 2) / 2 <= t) ++a;
+            while (a * (a + 1) / 2 > t) --a;
+            const int b = t - a * (a + 1) / 2;
+            const int i = j + 1 + a, k = j + 1 + b;
+            A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0 && info) info[blockIdx.x] = s_bad;
+        return;
+    }
+    if (tid == 0 && info) info[blockIdx.x] = 0;
+    // inverse: thread c owns column c of X = L^-1, stored at A[c][i] (i > c: the upper triangle), X[c][c] = dinv[c]
+    if (tid < n) {
+        const int c = tid;
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int k = 0; k < i; ++k) {
+                const double l = A[i * ld + k];                                  // broadcast
+                const double x = (k == c) ? dinv[c] : A[c * ld + k];             // x_c[k]; zero for k < c (masked below)
+                acc += (k >= c) ? l * x : 0.0;
+            }
+            if (i > c) A[c * ld + i] = -acc * dinv[i];
+        }
+    }
+    __syncthreads();
+    // S = L^-T = X^T: S[r][c] = X[c][r] = A[r][c] for c > r, dinv[r] on the diagonal, zero below
+    for (int idx = tid; idx < n * n; idx += CW_THREADS) {
+        const int r = idx / n, c = idx - r * n;
+        Sg[(long long)r * ldsg + c] = c > r ? A[r * ld + c] : (c == r ? dinv[r] : 0.0);
+    }
+}
 }  // namespace
+
+extern "C" int xps_chol_whiten_supported(int n) { return n >= 1 && n <= CW_MAX_N; }
+
+extern "C" int xps_chol_whiten_f64(const double* R, int64_t ldr, int64_t stride_r, double scale, double shift, double* A,
+                                   int64_t lda, int64_t stride_a, double* S, int64_t lds_, int64_t stride_s, int n, int batch,
+                                   int32_t* info, void* stream) {
+    XPS_CHECK_ARG(R && S && batch >= 0 && ldr >= n && lds_ >= n && (!A || lda >= n), "bad argument");
+    if (batch == 0) return XPS_OK;
+    if (!xps_chol_whiten_supported(n)) {
+        xps_set_error("xps_chol_whiten_f64: n = %d does not fit one workgroup's LDS (at most %d)", n, CW_MAX_N);
+        return XPS_E_INVALID;
+    }
+    const size_t lds = ((size_t)n * (n | 1) + n) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_whiten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((size_t)CW_MAX_N * (CW_MAX_N | 1) + CW_MAX_N) * sizeof(double))) != hipSuccess) {
+            xps_set_error("xps_chol_whiten_f64: cannot raise the dynamic LDS limit");
+            return XPS_E_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(chol_whiten_kernel, dim3(batch), dim3(CW_THREADS), lds, (hipStream_t)stream, R, (long long)ldr,
+                       (long long)stride_r, scale, shift, A, (long long)lda, (long long)stride_a, S, (long long)lds_,
+                       (long long)stride_s, n, (int*)info);
+    XPS_CHECK_LAUNCH();
+    return XPS_OK;
+}
 
 extern "C" int xps_jacobi_small_supported(int m, int n, int want_v) { return jacobi_small_vmode(m, n, want_v) >= 0; }
 

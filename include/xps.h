@@ -404,6 +404,16 @@ int xps_jacobi_sweeps_f64(double* W, int64_t ldw, double* V, int64_t ldv, int m,
  * `batch` matrices (stride_w / stride_v doubles apart) in one launch, one workgroup per matrix; sweeps run
  * until the largest |cos angle| of a sweep is <= tol or max_sweeps.  V (optional) is SET to the accumulated
  * rotations (identity on entry is implied).  sweeps_done[batch], off[batch]: optional device outputs.       */
+/* Whitening factors of a batch of small symmetric positive definite blocks: A_b = scale * R_b + shift * I = L L^T,
+ * S_b = L^-T (upper triangular; S_b^T A_b S_b = I).  Replaces the per-view R_b^-1/2 the reference obtains inside
+ * scipy.linalg.eigh(LHS, RHS) (mvlearn MCCA behind alignment/AlignMCCA.py:140-154; a generalised symmetric eigenproblem is
+ * reduced with the Cholesky factor of RHS there too).  R_b at R + b * stride_r (row-major, ldr; the lower triangle is read),
+ * A_b (optional, may be NULL) and S_b written at A + b * stride_a / S + b * stride_s.  n <= 136 (one workgroup, LDS resident).
+ * info[b] = 0, or j + 1 when pivot j is not positive (S_b is then not written). */
+int xps_chol_whiten_supported(int n);
+int xps_chol_whiten_f64(const double* R, int64_t ldr, int64_t stride_r, double scale, double shift, double* A, int64_t lda,
+                        int64_t stride_a, double* S, int64_t lds, int64_t stride_s, int n, int batch, int32_t* info,
+                        void* stream);
 int xps_jacobi_small_supported(int m, int n, int want_v);
 int xps_jacobi_small_f64(double* W, int64_t ldw, int64_t stride_w, double* V, int64_t ldv, int64_t stride_v,
                          int m, int n, int batch, int max_sweeps, double tol, int32_t* sweeps_done, double* off,

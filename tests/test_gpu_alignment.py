@@ -273,6 +273,53 @@ def test_align_mcca_vs_oracle_and_properties(pca_var):
 _north_star_views = {}
 
 
+@pytest.mark.parametrize('sizes', [[128] * 8, [30, 30, 17, 136, 1], [64]])
+def test_cholesky_whitening_factors_of_the_view_blocks_vs_numpy(sizes):
+    """xps_chol_whiten_f64 (the RHS reduction of the MCCA pencil, AlignMCCA._gevp): S_b = L_b^-T of A_b = scale G_bb + shift I,
+    against numpy's Cholesky factor; the regularised blocks written over LHS; a block that is not positive definite is refused."""
+    la = LA()
+    rng = np.random.default_rng(len(sizes))
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    D = int(offs[-1])
+    Z = rng.standard_normal((max(sizes) // 2 + 3, D))             # rank deficient blocks: only the shift makes them definite
+    G = Z.T @ Z
+    Gd = torch.from_numpy(G).cuda()
+    LHS = Gd.clone()
+    S = la.chol_whiten_blocks(Gd, offs, 0.5, 0.5, LHS)
+    assert S is not None
+    S, L2 = S.cpu().numpy(), LHS.cpu().numpy()
+    want_S, want_L = np.zeros_like(G), G.copy()
+    for b, n in enumerate(sizes):
+        sl = slice(offs[b], offs[b + 1])
+        Ab = 0.5 * G[sl, sl] + 0.5 * np.eye(n)
+        want_L[sl, sl] = Ab
+        want_S[sl, sl] = np.linalg.inv(np.linalg.cholesky(Ab)).T
+    np.testing.assert_array_equal(L2, want_L)
+    np.testing.assert_allclose(S, want_S, rtol=0, atol=1e-13 * np.abs(want_S).max())
+    W = S.T @ want_L @ S                                            # off-diagonal blocks untouched, diagonal blocks whitened
+    for b in range(len(sizes)):
+        sl = slice(offs[b], offs[b + 1])
+        np.testing.assert_allclose(W[sl, sl], np.eye(sizes[b]), atol=1e-12)
+    assert la.chol_whiten_blocks(Gd, offs, 1.0, -1e-3 * np.abs(G).max(), None) is None     # the largest block is rank deficient
+    assert la.chol_whiten_blocks(torch.eye(137, dtype=torch.float64).cuda(), np.array([0, 137]), 1.0, 0.0) is None   # > one workgroup's LDS
+
+
+def test_mcca_cholesky_and_eigendecomposition_whitening_give_the_same_transforms(monkeypatch):
+    """The two reductions of the pencil (Cholesky factors, default; symmetric R_b^-1/2 by Jacobi, XPS_MCCA_WHITEN=eig) give the same
+    eigenvalues and loadings to rounding."""
+    from cross_patient_speech_decoding_amd.utils.synthetic import make_patient
+    pats = [make_patient(p, 96, T=40, C=32) for p in range(4)]
+    feats, labs = [p[0] for p in pats], [p[1] for p in pats]
+    a = A().AlignMCCA(n_components=10, regs=0.5)
+    a.fit(feats, labs)
+    monkeypatch.setenv('XPS_MCCA_WHITEN', 'eig')
+    b = A().AlignMCCA(n_components=10, regs=0.5)
+    b.fit(feats, labs)
+    np.testing.assert_allclose(a.mcca.evals_, b.mcca.evals_, rtol=1e-11, atol=1e-12)
+    for la_, lb_ in zip(a.mcca.loadings_, b.mcca.loadings_):
+        np.testing.assert_allclose(la_, lb_, rtol=0, atol=1e-9 * np.abs(lb_).max())
+
+
 def _north_star_mcca_inputs():
     """Eight north-star patients (C = 128 channels, T = 200 samples, 64 shared conditions): 192 trials each --
     the condition-averaged views are the full 64 x 200 = 12 800 rows x 128 channels of the north-star fit (D = 1024);
