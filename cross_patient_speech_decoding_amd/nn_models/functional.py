@@ -365,10 +365,34 @@ def split4_wanted(T, B, H, ndir):
     return H > 256 and split4_supported(T, B, H, ndir)
 
 
+_saved_layout = {}
+
+
+def _stamp_saved(saved, B, H):
+    """The saved-gates buffer is private between the forward and the BPTT kernels and its layout depends on the launch form
+    (member-major on the cluster path, row-major on the single-workgroup path: csrc/xps_gru_cluster.hip): remember which form
+    wrote `saved`, so that a mode change between forward and backward is an error instead of silently wrong gradients."""
+    if saved is None:
+        return
+    if len(_saved_layout) > 4096:
+        _saved_layout.clear()
+    _saved_layout[saved.data_ptr()] = (lib().xps_get_gru_cluster_mode() != 0, B, H)
+
+
+def _check_saved(saved, B, H):
+    was = _saved_layout.get(saved.data_ptr())
+    now = (lib().xps_get_gru_cluster_mode() != 0, B, H)
+    if was is not None and was != now:
+        raise RuntimeError(f'GRU backward: the saved gates were written with cluster path {"on" if was[0] else "off"} (B, H = {was[1:]}) '
+                           f'but the backward runs with it {"on" if now[0] else "off"} (B, H = {now[1:]}): the launch form '
+                           '(set_gru_cluster_mode / XPS_GRU_CLUSTER) must not change between a forward and its backward')
+
+
 def _gru_forward(gi, w_hh, b_hh, h0, T, B, H, ndir, save, drop=None):
     dev = gi.device
     y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
     saved = torch.empty(ndir, T, B, 4 * H, dtype=_f32, device=dev) if save else None
+    _stamp_saved(saved, B, H)
     nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', T, B, H, ndir)
     ws = _ws(nbytes, dev)
     if nbytes > 16:
@@ -398,6 +422,7 @@ def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=Non
     dghn (ndir,T,B,H), dh0 (ndir,B,H) or None.  split4 (only where split4_supported): dgi / dghn hold XPS_FMT_SPLIT4
     groups -- GEMM operands to be described with rowmap(..., fmt=1), not fp32 values."""
     dev = y_ext.device
+    _check_saved(saved, B, H)
     if dy is not None and not dy.is_contiguous():
         dy = dy.contiguous()
     if dhn is not None and not dhn.is_contiguous():
@@ -966,6 +991,7 @@ class DecoderWideFn(torch.autograd.Function):
         tokens[0].fill_(int(start_token))
         hs = torch.empty(L + 2, B, H, dtype=_f32, device=dev)            # y_ext layout of a T = L sequence: slot s = h_{s-1}
         saved = torch.empty(1, L, B, 4 * H, dtype=_f32, device=dev) if save else None
+        _stamp_saved(saved, B, H)                                         # (L one-step forwards and one T = L backward share it)
         gi = torch.empty(B, 3 * H, dtype=_f32, device=dev)
         nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', 1, B, H, 1)
         _gru_status_register(dev)

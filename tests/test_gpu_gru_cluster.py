@@ -224,6 +224,27 @@ def test_persistent_under_concurrent_load(cluster_mode):
             assert torch.equal(p, q), f'repeat {rep}'
 
 
+def test_launch_form_change_between_forward_and_backward_is_refused(cluster_mode):
+    """The saved gates are member-major on the cluster path and row-major off it: a backward under the other launch form would
+    read them wrongly, so functional._gru_backward refuses (the forward stamps the buffer)."""
+    xf = XF()
+    T, B, H = 3, 256, 512
+    torch.manual_seed(0)
+    gi = torch.randn(1, T, B, 3 * H, device='cuda')
+    h0 = torch.zeros(1, B, H, device='cuda', requires_grad=True)
+    w = (0.05 * torch.randn(3 * H, H, device='cuda')).requires_grad_(True)
+    b = torch.zeros(3 * H, device='cuda', requires_grad=True)
+    cluster_mode('persistent')
+    y = xf.GRURecurFn.apply(gi, h0, 1, w, b)
+    cluster_mode('off')
+    with pytest.raises(RuntimeError, match='must not change between a forward and its backward'):
+        y.sum().backward()
+    cluster_mode('persistent')
+    y = xf.GRURecurFn.apply(gi, h0, 1, w, b)
+    y.sum().backward()                                   # same form: accepted
+    xf.check_gru_status()
+
+
 def test_cluster_path_is_bounded_by_its_largest_32_bit_buffer():
     """The cluster kernels address y_ext, saved and dgi through raw buffer descriptors (32-bit sizes / offsets).  The shape
     guard must bound the LARGEST of them (saved: ndir * T * B * 4H floats), not y_ext alone: at B = 2048, H = 512, both
