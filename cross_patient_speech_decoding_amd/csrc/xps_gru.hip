@@ -30,7 +30,8 @@ size_t xps_internal_gru_cluster_fwd_workspace(int B, int H, int ndir);
 size_t xps_internal_gru_cluster_bwd_workspace(int B, int H, int ndir);
 size_t xps_internal_gru_cluster_status_offset(int B, int H, int ndir);
 int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh, const float* h0,
-                                 float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st);
+                                 float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st,
+                                 float* y_split, float* yd_split, float drop_p, unsigned long long drop_seed);
 int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                  const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                                  int T, int B, int H, int ndir, void* workspace, hipStream_t st, int split_out);
@@ -1271,6 +1272,30 @@ extern "C" int xps_gru_seq_fwd_drop_f32(const float* gi, const float* const* w_h
                             workspace_bytes, stream);
 }
 
+// the cluster-persistent shapes in bf16x3 mode: the forward kernel's epilogue can also write XPS_FMT_SPLIT4 images of its outputs
+extern "C" int xps_gru_seq_fwd_images_supported(int T, int B, int H, int ndir) {
+    if (T < 1 || B < 1 || H < 1 || (ndir != 1 && ndir != 2)) return 0;
+    return (cluster_shape_ok(T, B, H, ndir) && xps_internal_gemm_mode() == 1 && H % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int xps_gru_seq_fwd_images_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                          const float* h0, float* y_ext, float* saved, int T, int B, int H, int ndir,
+                                          float* y_split, float* y_drop_split, float drop_p, uint64_t drop_seed,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    XPS_CHECK_ARG(gi && w_hh && b_hh && y_ext, "null argument");
+    XPS_CHECK_ARG(T >= 1 && B >= 1 && H >= 1 && (ndir == 1 || ndir == 2), "bad shape");
+    XPS_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "0 <= p < 1");
+    XPS_CHECK_ARG(xps_gru_seq_fwd_images_supported(T, B, H, ndir),
+                  "XPS_FMT_SPLIT4 images: cluster-persistent shapes in bf16x3 mode only (see xps_gru_seq_fwd_images_supported)");
+    XPS_CHECK_ARG(w_hh[0] && b_hh[0] && (ndir == 1 || (w_hh[1] && b_hh[1])), "null weight pointer");
+    if (!workspace || workspace_bytes < xps_gru_seq_fwd_f32_workspace(T, B, H, ndir)) {
+        xps_set_error("xps_gru_seq_fwd_images_f32: workspace too small");
+        return XPS_E_WORKSPACE;
+    }
+    return xps_internal_gru_cluster_fwd(gi, w_hh, b_hh, h0, y_ext, saved, T, B, H, ndir, workspace, (hipStream_t)stream,
+                                        y_split, y_drop_split, drop_p, (unsigned long long)drop_seed);
+}
+
 static int gru_seq_fwd_impl(const float* gi, const float* const* w_hh, const float* const* b_hh,
                             const float* h0, float* y_ext, float* saved,
                             int T, int B, int H, int ndir, float* y_drop, float drop_p, unsigned long long drop_seed,
@@ -1284,7 +1309,8 @@ static int gru_seq_fwd_impl(const float* gi, const float* const* w_hh, const flo
             xps_set_error("xps_gru_seq_fwd_f32: workspace too small");
             return XPS_E_WORKSPACE;
         }
-        return xps_internal_gru_cluster_fwd(gi, w_hh, b_hh, h0, y_ext, saved, T, B, H, ndir, workspace, (hipStream_t)stream);
+        return xps_internal_gru_cluster_fwd(gi, w_hh, b_hh, h0, y_ext, saved, T, B, H, ndir, workspace, (hipStream_t)stream,
+                                            nullptr, nullptr, 0.f, 0ull);
     }
     GruFwdParams p;
     p.gi = gi; p.h0 = h0; p.y_ext = y_ext; p.saved = saved;

@@ -267,6 +267,13 @@ struct ClFwd {
     int T, B, H, ndir, Bp, Mc, NR, nblk, CS;
     int s_begin, s_end, handoff;
     int saved_mm;          // saved gates member-major (H % 32 == 0), see the epilogue
+    // bf16x3 mode, optional (NULL: not written): XPS_FMT_SPLIT4 images for the GEMMs that read this layer's states -- of y_ext
+    // (all T + 2 slots: h_prev of the dW_hh products) and of dropout(y) (T slots: the next layer's projection and dW_ih) --
+    // written by the epilogue that holds the values, instead of one pass each over 168 MB (configs[3]) afterwards
+    float* y_split;
+    float* yd_split;
+    float drop_p, drop_scale;
+    unsigned long long drop_seed;
 };
 
 // 512 threads, two kinds of waves; every SIMD holds one of each, so the matrix pipe never waits for a memory latency or for
@@ -455,6 +462,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.xbuf_bytes, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y_ext, 0, (unsigned)((long long)(T + 2) * B * ldy * 4), RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(p.saved, 0, has_saved ? (unsigned)((long long)p.ndir * T * B * 4 * H * 4) : 0u, RSRC_FLAGS);
+    // (absent images: empty descriptors, the stores below are issued and dropped like those of dead lanes)
+    __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(p.y_split ? p.y_split : p.y_ext, 0, p.y_split ? (unsigned)((long long)(T + 2) * B * ldy * 4) : 0u, RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t ydr = __builtin_amdgcn_make_buffer_rsrc(p.yd_split ? p.yd_split : p.y_ext, 0, p.yd_split ? (unsigned)((long long)T * B * ldy * 4) : 0u, RSRC_FLAGS);
+    const bool images = BF && (p.y_split || p.yd_split);
     f32x4 bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -520,6 +531,16 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         CL_FENCE();
         const unsigned yo = live ? (unsigned)((((long long)(t + 1) * B + b) * ldy + dir * H + ju) * 4) : CL_OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, yo, 0, 0);
+        if constexpr (BF) {
+            if (images) {               // (wave-uniform; two stores, counted by the caller)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, split4_pack(o)), ysr, yo, 0, 0);
+                const long long e = ((long long)t * B + b) * ldy + dir * H + ju;        // element index in (T, B, ndir * H)
+                f32x4 v = o;
+                // (same decisions and arithmetic as split4_kernel / dropout_kernel: xps_common.h dropout_keep4 on the quad index)
+                if (p.drop_p > 0.f) v = v * dropout_keep4(p.drop_seed, e >> 2, p.drop_p) * p.drop_scale;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, split4_pack(v)), ydr, live ? (unsigned)(e * 4) : CL_OOB, 0, 0);
+            }
+        }
         if (has_saved) {
             // saved gates: private between this kernel and the BPTT kernels.  H % 32 == 0 (saved_mm): MEMBER-major --
             // [dir][t][member][trial][gate 4][32 units] -- so that a member streams 512 contiguous bytes per trial and its trials
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         if (it > it_begin) {
             take_products(it - it_begin);
             epilogue(s_pv, r_pv, ein[prv], prod);
-            younger += has_saved ? 5 : 1;
+            younger += (has_saved ? 5 : 1) + (images ? 2 : 0);
         }
         CL_FENCE();
         if (it + 2 < it_end) {
@@ -620,7 +641,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
 // h0 -> slots of y_ext and parity 0 of the exchange buffer (all Bp rows, all KP columns: pads are zero)
 template <bool BF>
 __global__ void gru_cluster_init_kernel(const float* __restrict__ h0, float* __restrict__ y_ext, void* __restrict__ xbuf,
-                                        int T, int B, int H, int ndir, int Bp, int KP, u32x4* __restrict__ header, int header_u4) {
+                                        int T, int B, int H, int ndir, int Bp, int KP, u32x4* __restrict__ header, int header_u4,
+                                        float* __restrict__ y_split) {
     // the workspace header (flags, XCC table, status block: header_u4 16-byte words) is zeroed here instead of by a memset of its
     // own in front of every launch (5 us each, five recurrence launches per configs[3] step)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < header_u4; i += gridDim.x * blockDim.x) header[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -637,6 +659,12 @@ __global__ void gru_cluster_init_kernel(const float* __restrict__ h0, float* __r
             const int ldy = ndir * H;
             *reinterpret_cast<f32x4*>(y_ext + ((long long)slot_h0 * B + b) * ldy + dir * H + k) = v;
             *reinterpret_cast<f32x4*>(y_ext + ((long long)slot_other * B + b) * ldy + dir * H + k) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+                if (y_split) {          // the same two slots of the XPS_FMT_SPLIT4 image of y_ext (ClFwd::y_split)
+                    *reinterpret_cast<f32x4*>(y_split + ((long long)slot_h0 * B + b) * ldy + dir * H + k) = split4_pack(v);
+                    *reinterpret_cast<f32x4*>(y_split + ((long long)slot_other * B + b) * ldy + dir * H + k) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
         }
         unsigned char* row = reinterpret_cast<unsigned char*>(xbuf) + ((long long)dir * Bp + b) * KP * 4;
         if constexpr (BF) {
@@ -1922,12 +1950,18 @@ size_t xps_internal_gru_cluster_status_offset(int B, int H, int ndir) {
 }
 
 int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh, const float* h0,
-                                 float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st) {
+                                 float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st,
+                                 float* y_split, float* yd_split, float drop_p, unsigned long long drop_seed) {
     const ClPlan pl = cl_plan(B, H, ndir);
     if (!pl.ok) { xps_set_error("gru cluster forward: unsupported shape"); return XPS_E_INVALID; }
     const bool bf = xps_internal_gemm_mode() == 1;
+    if ((y_split || yd_split) && (!bf || H % 4 != 0 || !cl_aligned16(y_split) || !cl_aligned16(yd_split))) {
+        xps_set_error("gru cluster forward: XPS_FMT_SPLIT4 images exist in bf16x3 mode only (H a multiple of 4, 16-byte aligned)");
+        return XPS_E_INVALID;
+    }
     ClFwd p;
     p.gi = gi; p.y_ext = y_ext; p.saved = saved;
+    p.y_split = y_split; p.yd_split = yd_split; p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
     for (int d = 0; d < 2; ++d) { p.w_hh[d] = w_hh[d < ndir ? d : 0]; p.b_hh[d] = b_hh[d < ndir ? d : 0]; }
     if (!cl_aligned16(gi) || !cl_aligned16(y_ext) || !cl_aligned16(saved) || !cl_aligned16(p.w_hh[0]) || !cl_aligned16(p.w_hh[1]) ||
         !cl_aligned16(p.b_hh[0]) || !cl_aligned16(p.b_hh[1]) || !cl_aligned16(h0) || !cl_aligned16(workspace)) {
@@ -1950,8 +1984,8 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
         const long long total = (long long)ndir * pl.Bp * (pl.KP / 4);
         const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         // (flags_bytes is a multiple of 256; the workspace is 16-byte aligned: checked above)
-        if (bf) hipLaunchKernelGGL(gru_cluster_init_kernel<true>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16));
-        else hipLaunchKernelGGL(gru_cluster_init_kernel<false>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16));
+        if (bf) hipLaunchKernelGGL(gru_cluster_init_kernel<true>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16), y_split);
+        else hipLaunchKernelGGL(gru_cluster_init_kernel<false>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16), (float*)nullptr);
     }
     p.sticky = cl_sticky();
     auto launch = [&](auto kernel, int lds) -> bool {

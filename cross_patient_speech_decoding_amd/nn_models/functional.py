@@ -417,6 +417,35 @@ def hprev_split_wanted(T, B, H, ndir):
             and os.environ.get('XPS_HPREV_SPLIT', '1') != '0' and os.environ.get('XPS_GEMM_DMA', '1') != '0')
 
 
+def fwd_images_wanted(T, B, H, ndir):
+    """OPT-IN (XPS_FWD_IMAGES=1): the forward recurrence kernel writes the XPS_FMT_SPLIT4 images its readers want
+    (xps_gru_seq_fwd_images_f32) -- of y_ext (h_prev of the dW_hh products, hprev_split_wanted) and, for a layer whose dropped
+    output feeds the next layer's GEMMs (layer_output_split4_ok), of dropout(y) -- instead of one xps_split4_f32 pass each over the
+    finished tensor.  Bit-identical (tests/test_gpu_split4.py) and three launches fewer per configs[3] step, but measured level
+    (round 4, serial profile: split4 passes 192 -> 0 us, forward kernels 1359 -> 1541 us per step; headline 6.60 vs 6.61 ms): two
+    more 1-KiB store instructions per gate wave and round go through the per-CU vector-memory pipe that paces the cluster kernels
+    (DESIGN 4.5.5), at the price the separate passes pay at HBM speed.  Not the default."""
+    return (os.environ.get('XPS_FWD_IMAGES', '0') == '1' and hprev_split_wanted(T, B, H, ndir)
+            and bool(lib().xps_gru_seq_fwd_images_supported(T, B, H, ndir)))
+
+
+def _gru_forward_images(gi, w_hh, b_hh, T, B, H, ndir, save, want_dropped, drop):
+    """_gru_forward (no h0) + the images: returns y_ext, saved, y_split (T + 2, B, ndir*H), y_drop_split (T, B, ndir*H) or None."""
+    dev = gi.device
+    y_ext = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev)
+    y_split = torch.empty(T + 2, B, ndir * H, dtype=_f32, device=dev) if save else None
+    yd_split = torch.empty(T, B, ndir * H, dtype=_f32, device=dev) if want_dropped else None
+    saved = torch.empty(ndir, T, B, 4 * H, dtype=_f32, device=dev) if save else None
+    _stamp_saved(saved, B, H)
+    nbytes = _gru_ws_bytes('xps_gru_seq_fwd_f32_workspace', T, B, H, ndir)
+    ws = _ws(nbytes, dev)
+    _gru_status_register(dev)
+    call('xps_gru_seq_fwd_images_f32', _ptr(gi), _ptr_array(w_hh), _ptr_array(b_hh), None, _ptr(y_ext), _ptr(saved), T, B, H, ndir,
+         _ptr(y_split), _ptr(yd_split), float(drop[0]) if (drop and want_dropped) else 0.0, int(drop[1]) if (drop and want_dropped) else 0,
+         _ptr(ws), nbytes, _stream())
+    return y_ext, saved, y_split, yd_split
+
+
 def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=None, split4=False):
     """BPTT kernel.  dy (T,B,ndir*H) or None, dhn (ndir,B,H) or None.  Returns dgi (ndir,T,B,3H),
     dghn (ndir,T,B,H), dh0 (ndir,B,H) or None.  split4 (only where split4_supported): dgi / dghn hold XPS_FMT_SPLIT4
@@ -608,12 +637,18 @@ class GRULayerFmtFn(torch.autograd.Function):
             drop = (float(drop_p), next_dropout_seed())
         ctx.drop = drop
         ctx.drop_fused = bool(drop is not None and fused_dropout_supported(T, B, H, ndir))
-        if ctx.drop_fused:
+        y_split = None
+        want_dropped = bool(fmt & FMT_Y_SPLIT4) and drop is not None and not ctx.drop_fused
+        if fwd_images_wanted(T, B, H, ndir) and (save or want_dropped):
+            # the recurrence kernel's epilogue writes the split4 images of y_ext (h_prev of dW_hh) and of the dropped output
+            y_ext, saved, y_split, y_drop = _gru_forward_images(gi, w_hh, b_hh, T, B, H, ndir, save, want_dropped, drop)
+        elif ctx.drop_fused:
             y_ext, saved, y_drop = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save, drop)
         else:
             y_ext, saved = _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
+        ctx.has_y_split = y_split is not None
         if save:
-            ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh)
+            ctx.save_for_backward(x, y_ext, saved, *w_ih, *w_hh, *([y_split] if y_split is not None else []))
         ctx.params = wb
         ctx.dims = (T, B, H, ndir, In, hn_mode)
         ctx.fmts = (x_fmt, w_fmt)
@@ -646,6 +681,7 @@ class GRULayerFmtFn(torch.autograd.Function):
         if dhn is not None and hn_mode == HN_SUM:          # the same (B, H) gradient reaches both directions
             dhn = dhn.unsqueeze(0).expand(ndir, B, H).contiguous()
         x, y_ext, saved, *w = ctx.saved_tensors
+        y_split = w.pop() if ctx.has_y_split else None
         w_ih, w_hh = w[:ndir], w[ndir:]
         x_fmt, w_fmt = ctx.fmts
         wb = ctx.params
@@ -661,7 +697,8 @@ class GRULayerFmtFn(torch.autograd.Function):
         # weight gradients first: on the side stream they depend on the recurrence kernel only, so they start
         # together with the input-gradient GEMM below instead of after it (and are out of the way earlier)
         y_fmt = 1 if (fmt and hprev_split_wanted(T, B, H, ndir)) else 0
-        y_src = torch.empty_like(y_ext) if y_fmt else y_ext           # (filled on the stream that carries the group: below)
+        have_img = bool(y_fmt and y_split is not None)                 # written by the forward kernel (fwd_images_wanted)
+        y_src = (y_split if have_img else torch.empty_like(y_ext)) if y_fmt else y_ext   # (else filled on the group's stream: below)
         probs, rets_hh = _recurrent_grad_problems(dgi, dghn, y_src, [wb[4 * d + 1] for d in range(ndir)],
                                                   [wb[4 * d + 3] for d in range(ndir)], T, B, H, ndir, fmt, y_fmt)
         rets_ih = []
@@ -677,7 +714,7 @@ class GRULayerFmtFn(torch.autograd.Function):
             rets_ih.append((rw, rb))
         direct = all(r[0] is None and r[1] is None for r in rets_ih + rets_hh)
         def launch_group(st):
-            if y_fmt:
+            if y_fmt and not have_img:
                 call('xps_split4_f32', _ptr(y_ext), _ptr(y_src), y_ext.numel(), 0.0, 0, _stream() if st is None else st)
             return gemm_tn_grouped(probs, dev, st)
         _launch_weight_grads(launch_group, dev, (dgi, dghn, x, y_ext, y_src), direct)

@@ -200,6 +200,17 @@ int xps_gru_seq_bwd_drop_f32(const float* dy, const float* dhn, const float* y_e
                              const float* const* w_hh, const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                              int T, int B, int H, int ndir, float drop_p, uint64_t drop_seed,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* xps_gru_seq_fwd_f32 that ALSO writes XPS_FMT_SPLIT4 images (see xps_rowmap) of its outputs, from the epilogue that holds the
+ * values (cluster-persistent shapes, 256 < H <= 512, bf16x3 mode: xps_gru_seq_fwd_images_supported): y_split (T + 2, B, ndir*H):
+ * the image of y_ext, slot for slot -- h_prev of the dW_hh products; y_drop_split (T, B, ndir*H): the image of
+ * dropout(y, drop_p, drop_seed) (drop_p = 0: of y) -- the input of the next layer's projection and dW_ih.  Either may be NULL.
+ * Same bits as xps_split4_f32 over the finished tensors (one pass each over 168 MB at configs[3]'s shape, which this replaces).
+ * Reference: the layer stack of nn_models/models.py:661-699 (torch.nn.GRU(dropout=p)). */
+int xps_gru_seq_fwd_images_supported(int T, int B, int H, int ndir);
+int xps_gru_seq_fwd_images_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                               const float* h0, float* y_ext, float* saved, int T, int B, int H, int ndir,
+                               float* y_split, float* y_drop_split, float drop_p, uint64_t drop_seed,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* The same backward with dgi / dghn written as XPS_FMT_SPLIT4 groups (see xps_rowmap): their only readers are GEMMs (weight
  * gradients, the layer's input gradient), and the BPTT kernels hold the bf16 hi / lo split of every gate gradient anyway.
  * bf16x3 mode; cluster-persistent shapes (256 < H <= 512) and the register-resident ones (H = 64 / 128):

@@ -193,6 +193,75 @@ def test_bptt_split4_outputs_equal_the_split_of_the_fp32_outputs(T, B, H, ndir, 
     np.testing.assert_array_equal(sghn.cpu().numpy().view(np.uint32), split4_host(dghn).view(np.uint32))
 
 
+@pytest.mark.parametrize('mode', ['persistent', 'steps'])
+@pytest.mark.parametrize('T,B,H,ndir,drop,save', [(4, 512, 512, 2, (0.3, 99), True), (3, 300, 448, 1, None, True),
+                                                  (2, 256, 500, 2, (0.5, 7), False), (1, 2048, 512, 1, None, True)])
+def test_forward_kernel_images_equal_the_split_passes_bitwise(T, B, H, ndir, drop, save, mode):
+    """xps_gru_seq_fwd_images_f32: the XPS_FMT_SPLIT4 images the cluster forward kernel writes from its epilogue (y_ext, all T + 2
+    slots; dropout(y)) equal xps_split4_f32 over the finished tensors bit for bit, and y_ext / saved equal the plain launch's."""
+    F = XF()
+    old = lib().xps_get_gru_cluster_mode()
+    F.set_gru_cluster_mode(mode)
+    try:
+        assert lib().xps_gru_seq_fwd_images_supported(T, B, H, ndir)
+        gi = rnd(ndir, T, B, 3 * H, seed=1)
+        w_hh = [rnd(3 * H, H, seed=2 + d, scale=H ** -0.5) for d in range(ndir)]
+        b_hh = [rnd(3 * H, seed=5 + d, scale=0.1) for d in range(ndir)]
+        y_ref, saved_ref = F._gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, save)
+        y_ext, saved, y_split, yd_split = F._gru_forward_images(gi, w_hh, b_hh, T, B, H, ndir, save, True, drop)
+        torch.cuda.synchronize()
+        F.check_gru_status()
+        assert torch.equal(y_ext, y_ref)
+        if save:
+            assert torch.equal(saved, saved_ref)
+            assert torch.equal(y_split.view(torch.int32), split4(y_ref).view(torch.int32))
+        else:
+            assert saved is None and y_split is None
+        want = split4(y_ref[1:T + 1].contiguous(), *(drop or (0.0, 0)))
+        assert torch.equal(yd_split.view(torch.int32), want.view(torch.int32))
+    finally:
+        lib().xps_set_gru_cluster_mode(old)
+
+
+def test_forward_images_are_refused_off_the_cluster_path():
+    F = XF()
+    assert not lib().xps_gru_seq_fwd_images_supported(4, 512, 128, 2)              # register-resident kernels
+    lib().xps_set_gemm_precision(0)
+    assert not lib().xps_gru_seq_fwd_images_supported(4, 512, 512, 2)              # fp32 products: no split4 operands
+    lib().xps_set_gemm_precision(1)
+    gi = rnd(1, 2, 64, 3 * 128, seed=1)
+    with pytest.raises(XpsError, match='images'):
+        F._gru_forward_images(gi, [rnd(384, 128)], [rnd(384)], 2, 64, 128, 1, True, False, None)
+
+
+def test_layer_with_forward_kernel_images_equals_the_split_passes(monkeypatch):
+    """Two-layer bidirectional encoder, training mode: XPS_FWD_IMAGES=1 (images from the recurrence kernel) against =0 (one
+    xps_split4_f32 pass per image): outputs and every gradient bit-identical."""
+    from cross_patient_speech_decoding_amd.nn_models.models import EncoderRNN
+    F = XF()
+    T, B, H, In = 8, 512, 512, 64
+    assert F.hprev_split_wanted(T, B, H, 2)
+    torch.manual_seed(3)
+    enc = EncoderRNN(In, H, 2, dropout=0.3).cuda().train()
+    x = rnd(T, B, In, seed=5)
+    wy, wl = rnd(T, B, 2 * H, seed=6), rnd(B, H, seed=7)
+
+    def run(flag):
+        monkeypatch.setenv('XPS_FWD_IMAGES', flag)
+        assert F.fwd_images_wanted(T, B, H, 2) == (flag == '1')
+        F._DROP_COUNTER[0] = 4321
+        enc.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y, last = enc.forward_tm_last(xg)
+        ((y * wy).sum() + (last * wl).sum()).backward()
+        torch.cuda.synchronize()
+        F.check_gru_status()
+        return [y.detach().clone(), last.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
+
+    for a, b in zip(run('0'), run('1')):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('H,In', [(512, 100), (500, 32), (128, 64)])
 def test_encoder_stack_with_split4_tensors_equals_the_fp32_tensor_path(H, In, monkeypatch):
     """Two-layer bidirectional encoder in TRAINING mode (inter-layer dropout on), XPS_SPLIT4=1 (dgi / dghn, the dropped
