@@ -67,6 +67,13 @@ __device__ inline void dma_piece(const unsigned char* sbase, unsigned voff, unsi
 #ifndef XPS_DMA_STAGGER
 #define XPS_DMA_STAGGER 0
 #endif
+// XPS_DMA_PAIR=1: two k-tiles per barrier (below).  Measured level with one barrier per k-tile (tools/proto/tn_dma.hip, dW_ih of
+// configs[3], two interleaved runs each: 318.7 / 321.5 us against 319.5 / 321.5 us, same bits) -- like the staggered and the
+// merged-barrier forms before it: with 65 % of the cycles on the matrix pipe at the 1.77 GHz the power limit leaves, removing
+// idle cycles does not buy time.  Compiled out.
+#ifndef XPS_DMA_PAIR
+#define XPS_DMA_PAIR 0
+#endif
 
 // acc += A[kbeg .. kbeg + 16 nkt)^T B[...] for the 256 x 256 tile at (m0, n0); A, B: split4 operands, [k][x], leading
 // dimensions lda / ldb (elements).  Ends with every DMA piece landed and a barrier (LDS is free).
@@ -122,7 +129,7 @@ __device__ inline void tn_dma_pipeline(f32x16 (&acc)[4][2], f32x16& cacc, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 #pragma unroll
-    for (int d = 0; d < DMA_D - 1; ++d)
+    for (int d = 0; d < (XPS_DMA_PAIR && DMA_D == 4 && !XPS_DMA_STAGGER ? 2 : DMA_D - 1); ++d)
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) piece(d, pc);
 #ifdef XPS_DMA_STAMP
@@ -207,6 +214,70 @@ __device__ inline void tn_dma_pipeline(f32x16 (&acc)[4][2], f32x16& cacc, const 
         } else {
             mma_group(std::integral_constant<int, 2>{}, H0.a2h, H0.a2l, H0.bh, H0.bl);
             mma_group(std::integral_constant<int, 3>{}, H0.a3h, H0.a3l, H0.bh, H0.bl);
+        }
+    } else if (XPS_DMA_PAIR && DMA_D == 4) {
+        // TWO k-tiles per barrier: the ring is two half-rings of two stages; behind the barrier that ends pair P - 1 the eight
+        // pieces of pair P + 1 go out (into the stages pair P - 1 was read from) while pair P is multiplied -- 64 KiB in flight per
+        // CU for two k-tile times.  Halves the barriers (stamps of the one-k-tile form: 464 of ~2100 cycles per k-tile and wave at
+        // the barrier, mostly skew between the eight waves) and the fragment-latency bubbles behind them (the second k-tile's
+        // fragments are requested under the first one's last MFMAs).  Same MFMA order per accumulator: same bits.
+        for (int kt = 0; kt < nkt; kt += 2) {
+            DSTAMP(t0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of k-tiles kt, kt + 1 have landed
+            DSTAMP(t1)
+            __builtin_amdgcn_s_barrier();                          // ... everybody's; and everybody is done reading kt - 2, kt - 1
+            DSTAMP(t2)
+            DSTAMP(t3)
+            const bool two = kt + 1 < nkt, more = kt + 2 < nkt, more2 = kt + 3 < nkt;      // (uniform)
+            const unsigned char* st0 = smem + (kt % DMA_D) * DMA_STAGE;
+            const unsigned char* st1 = smem + ((kt + 1) % DMA_D) * DMA_STAGE;
+            bf16x8 bh[2], bl[2], ah[2], al[2], ch[2], cl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) frag(st0 + fb + j * 128, bh[j], bl[j]);
+            frag(st0 + fa, ah[0], al[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { piece(kt + 2, 0); piece(kt + 2, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            // k-tile kt: row group i's six MFMAs under the requests of group i + 1 (group 3: of k-tile kt + 1's first fragments)
+            frag(st0 + fa + 128, ah[1], al[1]);
+            mma_group(std::integral_constant<int, 0>{}, ah[0], al[0], bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { piece(kt + 2, 2); piece(kt + 2, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            frag(st0 + fa + 256, ah[0], al[0]);
+            mma_group(std::integral_constant<int, 1>{}, ah[1], al[1], bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more2) { piece(kt + 3, 0); piece(kt + 3, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            frag(st0 + fa + 384, ah[1], al[1]);
+            mma_group(std::integral_constant<int, 2>{}, ah[0], al[0], bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more2) { piece(kt + 3, 2); piece(kt + 3, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) frag(st1 + fb + j * 128, ch[j], cl[j]);
+                frag(st1 + fa, ah[0], al[0]);
+            }
+            mma_group(std::integral_constant<int, 3>{}, ah[1], al[1], bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+                frag(st1 + fa + 128, ah[1], al[1]);
+                mma_group(std::integral_constant<int, 0>{}, ah[0], al[0], ch, cl);
+                __builtin_amdgcn_sched_barrier(0);
+                frag(st1 + fa + 256, ah[0], al[0]);
+                mma_group(std::integral_constant<int, 1>{}, ah[1], al[1], ch, cl);
+                __builtin_amdgcn_sched_barrier(0);
+                frag(st1 + fa + 384, ah[1], al[1]);
+                mma_group(std::integral_constant<int, 2>{}, ah[0], al[0], ch, cl);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group(std::integral_constant<int, 3>{}, ah[1], al[1], ch, cl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef XPS_DMA_STAMP
+            DSTAMP(t4)
+            s_wait += t1 - t0; s_bar += t2 - t1; s_dma += t3 - t2; s_mma += t4 - t3;
+#endif
         }
     } else
     for (int kt = 0; kt < nkt; ++kt) {
