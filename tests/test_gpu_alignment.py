@@ -304,6 +304,21 @@ def test_cholesky_whitening_factors_of_the_view_blocks_vs_numpy(sizes):
     assert la.chol_whiten_blocks(torch.eye(137, dtype=torch.float64).cuda(), np.array([0, 137]), 1.0, 0.0) is None   # > one workgroup's LDS
 
 
+def test_mcca_fit_is_deterministic():
+    """Two fits of the same 8 views at the north-star size (D = 1024, k = 30: Chebyshev subspace iteration with locking, split-K
+    products with a fixed-order reduce, Cholesky whitening) give the same bits: eigenvalues, loadings, transforms."""
+    feats, labs = _north_star_mcca_inputs()
+    a = A().AlignMCCA(n_components=30, regs=0.5)
+    oa = a.fit_transform(feats, labs)
+    b = A().AlignMCCA(n_components=30, regs=0.5)
+    ob = b.fit_transform(feats, labs)
+    np.testing.assert_array_equal(a.mcca.evals_, b.mcca.evals_)
+    for x, y in zip(a.mcca.loadings_, b.mcca.loadings_):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(oa, ob):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_mcca_cholesky_and_eigendecomposition_whitening_give_the_same_transforms(monkeypatch):
     """The two reductions of the pencil (Cholesky factors, default; symmetric R_b^-1/2 by Jacobi, XPS_MCCA_WHITEN=eig) give the same
     eigenvalues and loadings to rounding."""
