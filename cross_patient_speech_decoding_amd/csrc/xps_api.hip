@@ -13,7 +13,7 @@ void xps_set_error(const char* fmt, ...) {
 
 extern "C" const char* xps_last_error(void) { return g_err; }
 // 2: round 2 (xps_gru_seq_fwd_f32 takes a workspace; fused-dropout, decoder-select, big-tile and augmentation entry points added)
-extern "C" int xps_abi_version(void) { return 3; }
+extern "C" int xps_abi_version(void) { return 4; }
 
 // A stream at the LOWEST priority the device offers (torch exposes only "default" and "high"): the side stream
 // of the weight-gradient GEMMs must never be preferred over the critical path when a CU frees up.

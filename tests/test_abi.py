@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_channel(lib):
-    assert lib.xps_abi_version() == 3
+    assert lib.xps_abi_version() == 4
     rm = _lib.rowmap(4)
     rc = lib.xps_gemm_nt_f32(None, C.byref(rm), None, C.byref(rm), None, C.byref(rm), None, 4, 4, 4, 0, None)
     assert rc == -1
