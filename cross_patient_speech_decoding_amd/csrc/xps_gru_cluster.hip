@@ -186,6 +186,23 @@ __device__ inline void cl_dma4(const unsigned char* gsrc, unsigned l0, unsigned 
                  : "=&s"(keep) : "v"(gsrc), "s"(l0), "s"(l1), "s"(l2), "s"(l3));
 }
 
+// ALTERNATIVE exchange-row layout of the forward kernel (bf16x3 mode, compile-time: -DXPS_CL_FWD_PLANES=0; round 4): XPS_FMT_SPLIT4
+// groups (16 B: hi[0..3] | lo[0..3] of four consecutive k) instead of a hi plane and a lo plane, so that a gate-wave lane stores
+// ONE 16-byte vector and a member's 32 units are one FULL 128-byte line of the row (the planes: two 8-byte stores, two half lines).
+// An MFMA fragment needs the hi halves of TWO neighbouring groups: inside every 128-byte line (32 k = 8 groups) the row holds the
+// four EVEN groups first, then the four odd ones -- the producer stores group g of a line at slot (g & 1) * 4 + (g >> 1)
+// (cl_xslot), the DMA pieces copy lines as they lie; the k-quarter kq of a chunk reads groups 2 kq, 2 kq + 1 at line + 16 kq and
+// + 64 (per instruction the bank pattern of a plane read: conflict-free) and regroups the halves in registers.
+// Bit-identical, all cluster tests green -- and measured LEVEL on one box, three interleaved runs each (tools/bench_gru.py with
+// XPS_LIB_OVERRIDE): forward with saved gates 591-597 us both ways, forward without 478 vs 464 us (slower), configs[3] step 6.51-6.52
+// vs 6.49-6.53 ms.  The same layout in the BPTT kernel cost its launches 5-8 % (the contraction waves, which pace it, wait for
+// both reads of a fragment and regroup them before the first MFMA), as did a per-lane group permutation on the source side of the
+// DMA pieces.  The planes stay the default.
+__device__ inline unsigned cl_xslot(unsigned g) { return ((g & 1u) << 2) | ((g & 7u) >> 1); }
+#ifndef XPS_CL_FWD_PLANES
+#define XPS_CL_FWD_PLANES 1        // 0: the forward kernel's exchange rows as XPS_FMT_SPLIT4 groups (see above; A/B builds)
+#endif
+
 __device__ inline unsigned cl_lds_base(const unsigned char* smem) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) unsigned char*)smem;
 }
@@ -378,12 +395,21 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
                 // 16 steps (tile, chunk); the fragments of step i + 2 are requested before the MFMAs of step i (a ring of three,
                 // pinned with scheduling barriers: left alone the scheduler issues the reads of two steps right in front of
                 // their 18 MFMAs and exposes the LDS latency eight times per round)
-                const unsigned char* rp0 = tb + n * TS + (kbase + 8 * kq) * 2;
+                // (exchange rows are XPS_FMT_SPLIT4 groups; a line holds its even groups, then its odd ones: cl_xslot)
+                const unsigned char* rp0 = XPS_CL_FWD_PLANES ? tb + n * TS + (kbase + 8 * kq) * 2 : tb + n * TS + kh * PS + kq * 16;
                 bf16x8 bh[3], bl[3];
                 auto frag = [&](int i, bf16x8& h8, bf16x8& l8) {
-                    const unsigned char* rp = rp0 + (i >> 3) * 16 * TS + (i & 7) * 64;
-                    h8 = *reinterpret_cast<const bf16x8*>(rp);
-                    l8 = *reinterpret_cast<const bf16x8*>(rp + PS);
+                    if (XPS_CL_FWD_PLANES) {
+                        const unsigned char* rp = rp0 + (i >> 3) * 16 * TS + (i & 7) * 64;
+                        h8 = *reinterpret_cast<const bf16x8*>(rp);
+                        l8 = *reinterpret_cast<const bf16x8*>(rp + PS);
+                        return;
+                    }
+                    const unsigned char* rp = rp0 + (i >> 3) * 16 * TS + (i & 7) * 128;
+                    const bf16x8 ga = *reinterpret_cast<const bf16x8*>(rp);
+                    const bf16x8 gb = *reinterpret_cast<const bf16x8*>(rp + 64);
+                    h8 = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 8, 9, 10, 11);
+                    l8 = __builtin_shufflevector(ga, gb, 4, 5, 6, 7, 12, 13, 14, 15);
                 };
                 frag(0, bh[0], bl[0]);
                 frag(1, bh[1], bl[1]);
@@ -511,16 +537,25 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         if (sn + 1 < T) {
             const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
             if constexpr (BF) {
-                bf16x4 sh, sl;
+                // ONE 16-byte store per lane: hi[0..3] | lo[0..3] of the lane's four units (XPS_FMT_SPLIT4 group); a member's 32
+                // units are one FULL 128-byte line of the row (two 8-byte stores into a hi and a lo plane were two half lines)
+                if (XPS_CL_FWD_PLANES) {
+                    bf16x4 sh, sl;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { __bf16 x, c; bf_split(o[i], x, c); sh[i] = x; sl[i] = c; }
-                const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
-                if (fast) {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
+                    for (int i = 0; i < 4; ++i) { __bf16 x, c; bf_split(o[i], x, c); sh[i] = x; sl[i] = c; }
+                    const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 2u;
+                    if (fast) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                    }
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, off, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, off + KP * 2, 0, AUX_SC1);
+                    const u32x4 sp = __builtin_bit_cast(u32x4, split4_pack(o));
+                    const unsigned off = row * (unsigned)(KP * 4) + ((unsigned)ju & ~31u) * 4u + cl_xslot((unsigned)ju >> 2) * 16u;
+                    if (fast) __builtin_amdgcn_raw_buffer_store_b128(sp, xr, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(sp, xr, off, 0, AUX_SC1);
                 }
             } else {
                 const unsigned off = row * (unsigned)(KP * 4) + (unsigned)ju * 4u;
@@ -668,11 +703,15 @@ __global__ void gru_cluster_init_kernel(const float* __restrict__ h0, float* __r
         }
         unsigned char* row = reinterpret_cast<unsigned char*>(xbuf) + ((long long)dir * Bp + b) * KP * 4;
         if constexpr (BF) {
-            bf16x4 sh, sl;
+            if (XPS_CL_FWD_PLANES) {
+                bf16x4 sh, sl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { __bf16 a, c; bf_split(v[e], a, c); sh[e] = a; sl[e] = c; }
-            *reinterpret_cast<bf16x4*>(row + k * 2) = sh;
-            *reinterpret_cast<bf16x4*>(row + KP * 2 + k * 2) = sl;
+                for (int e = 0; e < 4; ++e) { __bf16 a, c; bf_split(v[e], a, c); sh[e] = a; sl[e] = c; }
+                *reinterpret_cast<bf16x4*>(row + k * 2) = sh;
+                *reinterpret_cast<bf16x4*>(row + KP * 2 + k * 2) = sl;
+            } else {
+                *reinterpret_cast<f32x4*>(row + (k & ~31) * 4 + cl_xslot((unsigned)k >> 2) * 16) = split4_pack(v);
+            }
         } else {
             *reinterpret_cast<f32x4*>(row + k * 4) = v;
         }
@@ -697,7 +736,7 @@ struct ClBwd {
     float* dghn;
     float* dh0;
     float* keep;                // [ndir][B][H]  z * dh of the step processed before
-    void* xbuf;                 // [2 parity][ndir][Bp/32][3 gates][32 trials] rows of KP elements
+    void* xbuf;                 // [2 parity][ndir][Bp/32][3 gates][32 trials] rows of KP elements (bf16 hi plane | lo plane, or f32)
     unsigned* flags;
     unsigned* xcc;
     unsigned* status;
@@ -869,6 +908,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             for (int g = 0; g < 3; ++g) {
                 const unsigned base = (chunk0 + g) * (unsigned)Cf::CHUNK_BYTES + rowoff;
                 if constexpr (BF) {
+                    // hi plane + lo plane of the row (XPS_FMT_SPLIT4 rows here cost 5-8 %: see XPS_CL_FWD_PLANES above)
                     bf16x4 sh, sl;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split((*gsrc[g])[i], a, c); sh[i] = a; sl[i] = c; }

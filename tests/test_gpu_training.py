@@ -41,7 +41,7 @@ def test_process_aligner_matches_oracle():
     np.testing.assert_allclose(z, ref_tar.transform(Xt.reshape(-1, Xt.shape[-1])[:50]), atol=2e-4)
 
 
-def test_process_aligner_multiview_mcca_runs_and_aligns():
+def test_process_aligner_multiview_mcca_matches_oracle_composition():
     from cross_patient_speech_decoding_amd.alignment import AlignMCCA
     from cross_patient_speech_decoding_amd.nn_models.data_utils.datamodules import process_aligner_multiview
     views = _pooled_views()
@@ -50,6 +50,21 @@ def test_process_aligner_multiview_mcca_runs_and_aligns():
     assert Xp.shape == (sum(v[0].shape[0] for v in views), 40, 4) and yp.shape == (Xp.shape[0], 3)
     z = tmap.transform(Xt.reshape(-1, Xt.shape[-1]))
     np.testing.assert_allclose(z.reshape(Xt.shape[0], 40, 4), Xp[:Xt.shape[0]].numpy(), atol=1e-4)
+    # against the oracle composition: PCA(0.95) per patient (oracle/align_oracle.pca_fit) -> oracle MCCA on the condition means ->
+    # every view through its own map, pooled; components up to sign (fixed by the first pooled sample with a clear value)
+    from oracle import align_oracle as ao, mcca_oracle as mo
+    dr = []
+    for x, _ in views:
+        _, zz = ao.pca_fit(x.reshape(-1, x.shape[-1]), 0.95)
+        dr.append(zz.reshape(x.shape[0], -1, zz.shape[-1]))
+    ref = mo.get_mcca_transforms(dr, [y for _, y in views], n_components=4, regs=0.5)
+    gaps = np.abs(np.diff(ref.evals_)) / np.abs(ref.evals_).max()
+    assert gaps.min() > 1e-6                                  # simple eigenvalues: the comparison below is meaningful
+    ref_pool = np.vstack([mo.mcca_transform(ref, v, i) for i, v in enumerate(dr)])
+    got = Xp.numpy().astype(np.float64)
+    for c in range(4):
+        sgn = np.sign(np.sum(got[..., c] * ref_pool[..., c]))
+        assert np.abs(got[..., c] - sgn * ref_pool[..., c]).max() <= 5e-4 * np.abs(ref_pool[..., c]).max(), c
 
 
 def test_trainer_fit_test_and_logged_metrics():

@@ -42,11 +42,6 @@ for prec in precs:
         xf.check_gru_status()
         b_tr = ev(lambda: xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False))
         diag = ''
-        if xf._gru_status_words:
-            w = xf._gru_status_words[-1]
-            st = w.storage_offset()
-            d = w._base[st:st + 24].view(torch.int32).tolist() if w._base is not None else None
-            diag = f' | last bwd launch: failed look-ahead polls {d[1]}, waited {d[2] / 100:.0f} us in total, longest {d[3] / 100:.1f} us; workgroups in one-XCD clusters {d[4]}, mixed {d[5]}' if d else ''
         xf.check_gru_status()
         by_f = 4 * ndir * T * B * (3 * H + H + 4 * H)
         by_b = 4 * ndir * T * B * (4 * H + H + H + 3 * H + H)
