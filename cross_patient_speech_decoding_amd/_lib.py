@@ -78,6 +78,7 @@ SIGNATURES = {
     'xps_gru_seq_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'xps_gru_seq_fused_dropout_supported': (_i, [_i, _i, _i, _i]),
     'xps_gru_seq_fwd_images_supported': (_i, [_i, _i, _i, _i]),
+    'xps_gru_seq_fwd_image_exchange_supported': (_i, [_i, _i, _i, _i]),
     'xps_gru_seq_fwd_images_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, C.c_uint64, _vp, _sz, _vp]),
     'xps_gru_seq_fwd_drop_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, C.c_uint64, _vp, _sz, _vp]),
     'xps_gru_seq_bwd_drop_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_uint64, _vp, _sz, _vp]),

@@ -35,6 +35,7 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
 int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float* y_ext, const float* saved,
                                  const float* const* w_hh_t, float* dgi, float* dghn, float* dh0,
                                  int T, int B, int H, int ndir, void* workspace, hipStream_t st, int split_out);
+bool xps_internal_gru_cluster_ximg_ok(int B, int H, int ndir);
 
 namespace {
 
@@ -1276,6 +1277,11 @@ extern "C" int xps_gru_seq_fwd_drop_f32(const float* gi, const float* const* w_h
 extern "C" int xps_gru_seq_fwd_images_supported(int T, int B, int H, int ndir) {
     if (T < 1 || B < 1 || H < 1 || (ndir != 1 && ndir != 2)) return 0;
     return (cluster_shape_ok(T, B, H, ndir) && xps_internal_gemm_mode() == 1 && H % 4 == 0) ? 1 : 0;
+}
+
+// ... and the image of y_ext costs nothing there: the launch uses it as its exchange buffer (H = 512, no pad trials; XPS_GRU_XIMG=0: never)
+extern "C" int xps_gru_seq_fwd_image_exchange_supported(int T, int B, int H, int ndir) {
+    return (xps_gru_seq_fwd_images_supported(T, B, H, ndir) && xps_internal_gru_cluster_ximg_ok(B, H, ndir)) ? 1 : 0;
 }
 
 extern "C" int xps_gru_seq_fwd_images_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,

@@ -203,6 +203,22 @@ __device__ inline unsigned cl_xslot(unsigned g) { return ((g & 1u) << 2) | ((g &
 #define XPS_CL_FWD_PLANES 1        // 0: the forward kernel's exchange rows as XPS_FMT_SPLIT4 groups (see above; A/B builds)
 #endif
 
+// image exchange (XIMG): lane 8 l + s of a DMA piece writes LDS slot s of line l and fetches global group 2 s (s < 4) or
+// 2 (s - 4) + 1 of that line: the standard XPS_FMT_SPLIT4 row in memory becomes the even | odd arrangement in LDS
+__device__ inline int cl_ximg_lane(int lane) { return (lane & ~7) | ((lane & 3) * 2 + ((lane >> 2) & 1)); }
+
+// two trials' rows from two base addresses (the image's rows lie ndir * H * 4 bytes apart: beyond the instruction's offset field)
+__device__ inline void cl_dma2x2(const unsigned char* g0, const unsigned char* g1, unsigned l0, unsigned l1, unsigned l2, unsigned l3) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1024 sc1\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc1\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off offset:1024 sc1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1), "s"(l0), "s"(l1), "s"(l2), "s"(l3));
+}
+
 __device__ inline unsigned cl_lds_base(const unsigned char* smem) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) unsigned char*)smem;
 }
@@ -305,9 +321,16 @@ struct ClFwd {
 // Round `it` = (step s, trials [32 r, 32 r + 32) of the cluster); one barrier per round.  During round it: contraction of
 // round it (buffer it & 1), pieces of round it + 1 into the other buffer, gate math of round it - 1, flag of round it - 2
 // (its exchange rows were complete before the last barrier), poll of the flags of round it + 2.
-template <int KSPLIT, bool BF>
+// XIMG (bf16x3 mode, H == KP, B % 32 == 0, training): the exchange buffer IS the XPS_FMT_SPLIT4 image of y_ext (ClFwd::y_split) -- a
+// member publishes h_t by ONE 16-byte store per lane into slot t + 1 of the image (standard group order), the operand image of the
+// next step is moved from the rows of that slot by LDS-DMA pieces whose lanes pick the groups in even / odd order (cl_ximg_lane; the
+// fragment reads are those of the XPS_CL_FWD_PLANES = 0 layout), and the weight-gradient GEMMs read h_prev from the same image: no
+// ring buffer traffic of its own, one store per lane and round fewer, and no xps_split4_f32 pass over y_ext afterwards.
+template <int KSPLIT, bool BF, bool XIMG = false>
 __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     static_assert(KSPLIT == 2, "the cluster kernels cover 256 < H <= 512");
+    static_assert(!XIMG || BF, "the image exchange exists in bf16x3 mode only");
+    constexpr bool SPLITROWS = XIMG || !XPS_CL_FWD_PLANES;       // exchange rows / LDS image as split4 groups (even | odd per line)
     using Cf = ClCfg<KSPLIT, BF, 1>;
     constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,7 +355,14 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     // gate wave 4 + h moves pieces [16 h, 16 h + 16) of a round (trials 8 h .. 8 h + 7 of the 32) in four groups of four
     const int mvw = wave & 3;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
+    const long long xrow = XIMG ? (long long)ldy * 4 : (long long)KP * 4;      // bytes between the rows of two trials
     auto dma_src = [&](int s_, int r_) -> const unsigned char* {
+        if constexpr (XIMG) {
+            // rows of slot_prev(s_) of the image: trial b = m_base + 32 r_ + 8 mvw + ..., this direction's H = KP elements
+            const int slot_prev = (dir == 0) ? s_ : T + 1 - s_;
+            return reinterpret_cast<const unsigned char*>(p.y_split) +
+                   (((long long)slot_prev * B + m_base + 32 * r_ + 8 * mvw) * ldy + dir * H) * 4 + cl_ximg_lane(lane) * 16;
+        }
         return xb + (size_t)(((s_ & 1) * p.ndir + dir) * p.Bp + m_base + 32 * r_) * (KP * 4) + (size_t)(mvw * 16) * 1024 + lane * 16;
     };
     auto dma_group = [&](const unsigned char* src, int buf, int grp) {      // grp = 0 .. 3 (compile time at every call site)
@@ -340,7 +370,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         const unsigned base = lds0 + (unsigned)(buf * TILE) + (unsigned)((j >> 1) * TS);
         // pieces j .. j + 3 = (trial, half) (t, 0), (t, 1), (t + 1, 0), (t + 1, 1); the immediates add 0, 1024, 2048, 3072
         const unsigned h = BF ? PS : 1024;
-        cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
+        if constexpr (XIMG) cl_dma2x2(src + (2 * grp) * xrow, src + (2 * grp + 1) * xrow, base, base + h - 1024, base + TS, base + TS + h - 1024);
+        else cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
     };
 
     if (wave < 4) {
@@ -396,10 +427,10 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
                 // pinned with scheduling barriers: left alone the scheduler issues the reads of two steps right in front of
                 // their 18 MFMAs and exposes the LDS latency eight times per round)
                 // (exchange rows are XPS_FMT_SPLIT4 groups; a line holds its even groups, then its odd ones: cl_xslot)
-                const unsigned char* rp0 = XPS_CL_FWD_PLANES ? tb + n * TS + (kbase + 8 * kq) * 2 : tb + n * TS + kh * PS + kq * 16;
+                const unsigned char* rp0 = !SPLITROWS ? tb + n * TS + (kbase + 8 * kq) * 2 : tb + n * TS + kh * PS + kq * 16;
                 bf16x8 bh[3], bl[3];
                 auto frag = [&](int i, bf16x8& h8, bf16x8& l8) {
-                    if (XPS_CL_FWD_PLANES) {
+                    if constexpr (!SPLITROWS) {
                         const unsigned char* rp = rp0 + (i >> 3) * 16 * TS + (i & 7) * 64;
                         h8 = *reinterpret_cast<const bf16x8*>(rp);
                         l8 = *reinterpret_cast<const bf16x8*>(rp + PS);
@@ -491,7 +522,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
     // (absent images: empty descriptors, the stores below are issued and dropped like those of dead lanes)
     __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(p.y_split ? p.y_split : p.y_ext, 0, p.y_split ? (unsigned)((long long)(T + 2) * B * ldy * 4) : 0u, RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t ydr = __builtin_amdgcn_make_buffer_rsrc(p.yd_split ? p.yd_split : p.y_ext, 0, p.yd_split ? (unsigned)((long long)T * B * ldy * 4) : 0u, RSRC_FLAGS);
-    const bool images = BF && (p.y_split || p.yd_split);
+    const bool images = BF && !XIMG && (p.y_split || p.yd_split);       // extra image stores of the ring-buffer form (opt-in)
+    const bool img_drop = XIMG && p.yd_split;                            // XIMG: the dropped image stays an extra store
     f32x4 bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -534,12 +566,17 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
             o[i] = live ? ng[i] + zg[i] * (hp[i] - ng[i]) : 0.f;
         }
         CL_FENCE();
-        if (sn + 1 < T) {
+        if constexpr (XIMG) {
+            // the exchange row IS the image row of slot t + 1 (an output: written for the last step too); same offset as y_ext's
+            const u32x4 sp = __builtin_bit_cast(u32x4, split4_pack(o));
+            const unsigned xo = live ? (unsigned)((((long long)(t + 1) * B + b) * ldy + dir * H + ju) * 4) : CL_OOB;
+            if (fast) __builtin_amdgcn_raw_buffer_store_b128(sp, ysr, xo, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(sp, ysr, xo, 0, AUX_SC1);
+        } else if (sn + 1 < T) {
             const unsigned row = (unsigned)((((sn + 1) & 1) * p.ndir + dir) * p.Bp + b);
             if constexpr (BF) {
-                // ONE 16-byte store per lane: hi[0..3] | lo[0..3] of the lane's four units (XPS_FMT_SPLIT4 group); a member's 32
-                // units are one FULL 128-byte line of the row (two 8-byte stores into a hi and a lo plane were two half lines)
-                if (XPS_CL_FWD_PLANES) {
+                // (SPLITROWS: ONE 16-byte store per lane, hi[0..3] | lo[0..3] of its four units; a member's 32 units = one full line)
+                if constexpr (!SPLITROWS) {
                     bf16x4 sh, sl;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { __bf16 x, c; bf_split(o[i], x, c); sh[i] = x; sl[i] = c; }
@@ -567,8 +604,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         const unsigned yo = live ? (unsigned)((((long long)(t + 1) * B + b) * ldy + dir * H + ju) * 4) : CL_OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, yo, 0, 0);
         if constexpr (BF) {
-            if (images) {               // (wave-uniform; two stores, counted by the caller)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, split4_pack(o)), ysr, yo, 0, 0);
+            if (images || img_drop) {   // (wave-uniform; two stores / one, counted by the caller)
+                if (!XIMG) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, split4_pack(o)), ysr, yo, 0, 0);
                 const long long e = ((long long)t * B + b) * ldy + dir * H + ju;        // element index in (T, B, ndir * H)
                 f32x4 v = o;
                 // (same decisions and arithmetic as split4_kernel / dropout_kernel: xps_common.h dropout_keep4 on the quad index)
@@ -635,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_fwd_kernel(ClFwd p) {
         if (it > it_begin) {
             take_products(it - it_begin);
             epilogue(s_pv, r_pv, ein[prv], prod);
-            younger += (has_saved ? 5 : 1) + (images ? 2 : 0);
+            younger += (has_saved ? 5 : 1) + (images ? 2 : 0) + (img_drop ? 1 : 0);
         }
         CL_FENCE();
         if (it + 2 < it_end) {
@@ -701,6 +738,7 @@ __global__ void gru_cluster_init_kernel(const float* __restrict__ h0, float* __r
                 }
             }
         }
+        if (!xbuf) continue;                               // (image exchange: slot_h0 of y_split, written above, is the first operand)
         unsigned char* row = reinterpret_cast<unsigned char*>(xbuf) + ((long long)dir * Bp + b) * KP * 4;
         if constexpr (BF) {
             if (XPS_CL_FWD_PLANES) {
@@ -1810,7 +1848,7 @@ struct ClDev {
     // [kernel kind: forward / 1-D BPTT / 2-D BPTT][fp32 / bf16x3]; the (kernel, LDS bytes) pair is part of the key: the 2-D BPTT
     // kernel has another LDS block and register count than the 1-D one.  Relaxed atomics: the autograd thread and
     // the main thread may both ask; either computes the same value.
-    std::atomic<int> resident[3][2];
+    std::atomic<int> resident[4][2];
     ClDev() { for (auto& k : resident) for (auto& v : k) v.store(-1, std::memory_order_relaxed); }
     unsigned* sticky = nullptr;
 };
@@ -1934,7 +1972,8 @@ bool cl_set_lds(K kernel, int bytes) {
 inline bool cl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // workgroups of `kernel` (512 threads, `lds` bytes) the current device holds at once; cached per device and kernel kind
-// (kind: 0 forward, 1 one-dimensional BPTT, 2 two-dimensional BPTT -- each kind is ONE (kernel, lds) pair per precision)
+// (kind: 0 forward, 1 one-dimensional BPTT, 2 two-dimensional BPTT, 3 forward with the image exchange -- each kind is ONE (kernel, lds)
+// pair per precision)
 template <typename K>
 int cl_resident(K kernel, int lds, int kind, int bf) {
     const int dev = cl_device();
@@ -1948,6 +1987,12 @@ int cl_resident(K kernel, int lds, int kind, int bf) {
         slot.store(v, std::memory_order_relaxed);
     }
     return v;
+}
+
+// XPS_GRU_XIMG=0: the forward kernel keeps its ring buffer even when it writes the image of y_ext (A/B; read per call)
+bool cl_ximg_enabled() {
+    const char* e = getenv("XPS_GRU_XIMG");
+    return !(e && e[0] == '0');
 }
 
 unsigned* cl_sticky() {
@@ -1989,6 +2034,12 @@ size_t xps_internal_gru_cluster_status_offset(int B, int H, int ndir) {
     return pl.ok ? pl.flags_bytes - 256 : 0;
 }
 
+// the forward launch can use the XPS_FMT_SPLIT4 image of y_ext as its exchange buffer (bf16x3 mode is the caller's check)
+bool xps_internal_gru_cluster_ximg_ok(int B, int H, int ndir) {
+    const ClPlan pl = cl_plan(B, H, ndir);
+    return pl.ok && H == pl.KP && pl.Bp == B && cl_ximg_enabled();
+}
+
 int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh, const float* h0,
                                  float* y_ext, float* saved, int T, int B, int H, int ndir, void* workspace, hipStream_t st,
                                  float* y_split, float* yd_split, float drop_p, unsigned long long drop_seed) {
@@ -2002,6 +2053,8 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
     ClFwd p;
     p.gi = gi; p.y_ext = y_ext; p.saved = saved;
     p.y_split = y_split; p.yd_split = yd_split; p.drop_p = drop_p; p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
+    // the image of y_ext as the exchange buffer itself (gru_cluster_fwd_kernel<.., XIMG>): rows of exactly KP elements, no pad trials
+    const bool ximg = bf && y_split && H == pl.KP && pl.Bp == B && cl_ximg_enabled();
     for (int d = 0; d < 2; ++d) { p.w_hh[d] = w_hh[d < ndir ? d : 0]; p.b_hh[d] = b_hh[d < ndir ? d : 0]; }
     if (!cl_aligned16(gi) || !cl_aligned16(y_ext) || !cl_aligned16(saved) || !cl_aligned16(p.w_hh[0]) || !cl_aligned16(p.w_hh[1]) ||
         !cl_aligned16(p.b_hh[0]) || !cl_aligned16(p.b_hh[1]) || !cl_aligned16(h0) || !cl_aligned16(workspace)) {
@@ -2024,14 +2077,14 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
         const long long total = (long long)ndir * pl.Bp * (pl.KP / 4);
         const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         // (flags_bytes is a multiple of 256; the workspace is 16-byte aligned: checked above)
-        if (bf) hipLaunchKernelGGL(gru_cluster_init_kernel<true>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16), y_split);
+        if (bf) hipLaunchKernelGGL(gru_cluster_init_kernel<true>, dim3(blocks), dim3(256), 0, st, h0, y_ext, ximg ? (void*)nullptr : p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16), y_split);
         else hipLaunchKernelGGL(gru_cluster_init_kernel<false>, dim3(blocks), dim3(256), 0, st, h0, y_ext, p.xbuf, T, B, H, ndir, pl.Bp, pl.KP, (u32x4*)ws, (int)(pl.flags_bytes / 16), (float*)nullptr);
     }
     p.sticky = cl_sticky();
     auto launch = [&](auto kernel, int lds) -> bool {
         if (!cl_set_lds(kernel, lds)) return false;
         // the persistent form spins across workgroups: only when the device holds the whole grid at once
-        const bool persistent = cl_mode() == 2 && pl.grid <= cl_resident(kernel, lds, 0, bf ? 1 : 0);
+        const bool persistent = cl_mode() == 2 && pl.grid <= cl_resident(kernel, lds, ximg ? 3 : 0, bf ? 1 : 0);
         if (persistent) {
             p.s_begin = 0; p.s_end = T; p.handoff = 1;
             hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
@@ -2045,7 +2098,8 @@ int xps_internal_gru_cluster_fwd(const float* gi, const float* const* w_hh, cons
         return true;
     };
     bool ok;
-    ok = bf ? launch(gru_cluster_fwd_kernel<2, true>, ClCfg<2, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<2, false>, ClCfg<2, false, 1>::LDS_BYTES);
+    ok = ximg ? launch(gru_cluster_fwd_kernel<2, true, true>, ClCfg<2, true, 1>::LDS_BYTES)
+       : bf ? launch(gru_cluster_fwd_kernel<2, true>, ClCfg<2, true, 1>::LDS_BYTES) : launch(gru_cluster_fwd_kernel<2, false>, ClCfg<2, false, 1>::LDS_BYTES);
     if (!ok) { xps_set_error("gru cluster forward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
     XPS_CHECK_LAUNCH();
     return XPS_OK;

@@ -417,14 +417,22 @@ def hprev_split_wanted(T, B, H, ndir):
             and os.environ.get('XPS_HPREV_SPLIT', '1') != '0' and os.environ.get('XPS_GEMM_DMA', '1') != '0')
 
 
+def fwd_ysplit_wanted(T, B, H, ndir):
+    """The forward recurrence launch writes the XPS_FMT_SPLIT4 image of y_ext that the weight-gradient group reads h_prev from
+    (hprev_split_wanted) where the launch can use that image AS its in-kernel exchange buffer (xps_gru_seq_fwd_image_exchange_supported:
+    H = 512, no pad trials): the image replaces the ring buffer's stores, and the xps_split4_f32 pass over y_ext in the backward
+    (65 us and 0.34 GB per layer at configs[3]'s shape) is gone.  XPS_FWD_YSPLIT=0: the pass."""
+    return (os.environ.get('XPS_FWD_YSPLIT', '1') != '0' and hprev_split_wanted(T, B, H, ndir)
+            and bool(lib().xps_gru_seq_fwd_image_exchange_supported(T, B, H, ndir)))
+
+
 def fwd_images_wanted(T, B, H, ndir):
-    """OPT-IN (XPS_FWD_IMAGES=1): the forward recurrence kernel writes the XPS_FMT_SPLIT4 images its readers want
-    (xps_gru_seq_fwd_images_f32) -- of y_ext (h_prev of the dW_hh products, hprev_split_wanted) and, for a layer whose dropped
-    output feeds the next layer's GEMMs (layer_output_split4_ok), of dropout(y) -- instead of one xps_split4_f32 pass each over the
-    finished tensor.  Bit-identical (tests/test_gpu_split4.py) and three launches fewer per configs[3] step, but measured level
-    (round 4, serial profile: split4 passes 192 -> 0 us, forward kernels 1359 -> 1541 us per step; headline 6.60 vs 6.61 ms): two
-    more 1-KiB store instructions per gate wave and round go through the per-CU vector-memory pipe that paces the cluster kernels
-    (DESIGN 4.5.5), at the price the separate passes pay at HBM speed.  Not the default."""
+    """OPT-IN (XPS_FWD_IMAGES=1): the forward launch ALSO writes the image of dropout(y) for a layer whose dropped output feeds the
+    next layer's GEMMs (layer_output_split4_ok) -- and, off the image-exchange shapes, the image of y_ext as an extra store --
+    instead of xps_split4_f32 passes over the finished tensors.  Bit-identical (tests/test_gpu_split4.py), measured level (round 4,
+    serial profile: split4 passes 192 -> 0 us, forward kernels 1359 -> 1541 us per step; headline 6.60 vs 6.61 ms): an extra 1-KiB
+    store instruction per gate wave and round goes through the per-CU vector-memory pipe that paces the cluster kernels,
+    at the price the separate pass pays at HBM speed.  Not the default."""
     return (os.environ.get('XPS_FWD_IMAGES', '0') == '1' and hprev_split_wanted(T, B, H, ndir)
             and bool(lib().xps_gru_seq_fwd_images_supported(T, B, H, ndir)))
 
@@ -638,8 +646,9 @@ class GRULayerFmtFn(torch.autograd.Function):
         ctx.drop = drop
         ctx.drop_fused = bool(drop is not None and fused_dropout_supported(T, B, H, ndir))
         y_split = None
-        want_dropped = bool(fmt & FMT_Y_SPLIT4) and drop is not None and not ctx.drop_fused
-        if fwd_images_wanted(T, B, H, ndir) and (save or want_dropped):
+        opt_in = fwd_images_wanted(T, B, H, ndir)
+        want_dropped = opt_in and bool(fmt & FMT_Y_SPLIT4) and drop is not None and not ctx.drop_fused
+        if (save and (opt_in or fwd_ysplit_wanted(T, B, H, ndir))) or want_dropped:
             # the recurrence kernel's epilogue writes the split4 images of y_ext (h_prev of dW_hh) and of the dropped output
             y_ext, saved, y_split, y_drop = _gru_forward_images(gi, w_hh, b_hh, T, B, H, ndir, save, want_dropped, drop)
         elif ctx.drop_fused:

@@ -207,6 +207,10 @@ int xps_gru_seq_bwd_drop_f32(const float* dy, const float* dhn, const float* y_e
  * Same bits as xps_split4_f32 over the finished tensors (one pass each over 168 MB at configs[3]'s shape, which this replaces).
  * Reference: the layer stack of nn_models/models.py:661-699 (torch.nn.GRU(dropout=p)). */
 int xps_gru_seq_fwd_images_supported(int T, int B, int H, int ndir);
+/* 1: for this shape the launch uses y_split as its in-kernel exchange buffer (H = 512, batch without pad trials): the image then
+ * REPLACES the ring buffer's stores (one store per lane and round fewer) instead of adding one; callers ask for y_split by default
+ * only where this holds. */
+int xps_gru_seq_fwd_image_exchange_supported(int T, int B, int H, int ndir);
 int xps_gru_seq_fwd_images_f32(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                const float* h0, float* y_ext, float* saved, int T, int B, int H, int ndir,
                                float* y_split, float* y_drop_split, float drop_p, uint64_t drop_seed,

@@ -240,7 +240,8 @@ def test_layer_with_forward_kernel_images_equals_the_split_passes(monkeypatch):
     from cross_patient_speech_decoding_amd.nn_models.models import EncoderRNN
     F = XF()
     T, B, H, In = 8, 512, 512, 64
-    assert F.hprev_split_wanted(T, B, H, 2)
+    assert F.hprev_split_wanted(T, B, H, 2) and F.fwd_ysplit_wanted(T, B, H, 2)
+    assert lib().xps_gru_seq_fwd_image_exchange_supported(T, B, H, 2) and not lib().xps_gru_seq_fwd_image_exchange_supported(T, 300, 448, 1)
     torch.manual_seed(3)
     enc = EncoderRNN(In, H, 2, dropout=0.3).cuda().train()
     x = rnd(T, B, In, seed=5)
@@ -258,7 +259,12 @@ def test_layer_with_forward_kernel_images_equals_the_split_passes(monkeypatch):
         F.check_gru_status()
         return [y.detach().clone(), last.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
 
-    for a, b in zip(run('0'), run('1')):
+    base = run('0')                                      # (default: y_ext's image is the forward launch's exchange buffer)
+    for a, b in zip(base, run('1')):
+        assert torch.equal(a, b)
+    monkeypatch.setenv('XPS_FWD_YSPLIT', '0')            # ring-buffer exchange + one xps_split4_f32 pass per image
+    assert not F.fwd_ysplit_wanted(T, B, H, 2)
+    for a, b in zip(base, run('0')):
         assert torch.equal(a, b)
 
 
