@@ -454,6 +454,14 @@ def _gru_forward_images(gi, w_hh, b_hh, T, B, H, ndir, save, want_dropped, drop)
     return y_ext, saved, y_split, yd_split
 
 
+def gru_forward_training_form(gi, w_hh, b_hh, T, B, H, ndir):
+    """The forward recurrence launch a training step of this shape issues (probes in bench.py / tools/): with the image of y_ext as
+    its exchange buffer where fwd_ysplit_wanted, else the plain launch.  Returns (y_ext, saved)."""
+    if fwd_ysplit_wanted(T, B, H, ndir):
+        return _gru_forward_images(gi, w_hh, b_hh, T, B, H, ndir, True, False, None)[:2]
+    return _gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, True)
+
+
 def _gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, drop=None, split4=False):
     """BPTT kernel.  dy (T,B,ndir*H) or None, dhn (ndir,B,H) or None.  Returns dgi (ndir,T,B,3H),
     dghn (ndir,T,B,H), dh0 (ndir,B,H) or None.  split4 (only where split4_supported): dgi / dghn hold XPS_FMT_SPLIT4

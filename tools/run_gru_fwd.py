@@ -13,7 +13,7 @@ if os.environ.get('GRID'):          # 1: the 4 x 4 BPTT grid
     from cross_patient_speech_decoding_amd import _lib
     _lib.lib().xps_set_gru_bptt_grid(int(os.environ['GRID']))
 for _ in range(5):
-    y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
+    y_ext, saved = xf.gru_forward_training_form(gi, ws, bs, T, B, H, ndir)       # (the form a training step launches)
     if os.environ.get('BWD'):
         xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False)
 torch.cuda.synchronize()
