@@ -613,6 +613,9 @@ def main():
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='configs3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--headline-only', action='store_true', help='skip the sub-records')
+    ap.add_argument('--no-probes', action='store_true',
+                    help='profiling runs only: skip the roofline probes too (their re-issued launches would be counted into a per-step '
+                         'kernel profile); the line then has no roofline')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default=None,
                     help='product precision of the matrix kernels (default: the library default, bf16x3)')
     args = ap.parse_args()
@@ -701,7 +704,9 @@ def main():
         out['config']['collective'] = (f'RCCL (torch.distributed backend {backend!r}) world {world}: SyncBN statistics + flat gradient '
                                        f'all-reduce per step' if world > 1 else 'none (single process)')
         out['rccl_world'] = world if (world > 1 and backend == 'nccl') else (0 if world == 1 else None)
-        if world == 1:
+        if world == 1 and args.no_probes:
+            out['roofline'] = None
+        elif world == 1:
             # (single process only: the roofline probes re-issue launches, a capture runs one more training step)
             try:
                 out['roofline'] = (roofline_cluster(model, c, dev) if name == 'configs3'

@@ -19,10 +19,10 @@ pmc() {  # name, counters, env, script
   env $3 rocprofv3 --pmc $2 --output-format csv -d /tmp/c_$1 -o x -- python3 $R/$4 > /tmp/c_$1.log 2>&1
   cp $(find /tmp/c_$1 -name '*counter_collection.csv' | head -1) /tmp/c_$1.csv
 }
-prof h512_serial XPS_OVERLAP_WGRAD=0 --workload configs3 --steps 10 --warmup 3 --headline-only --no-cpu-baseline &&
-prof h512_fp32_serial XPS_OVERLAP_WGRAD=0 --workload configs3 --precision fp32 --steps 10 --warmup 3 --headline-only --no-cpu-baseline &&
-prof cfg2_serial XPS_OVERLAP_WGRAD=0 --workload configs1 --steps 20 --warmup 5 --headline-only --no-cpu-baseline &&
-prof h512_overlap XPS_OVERLAP_WGRAD=1 --workload configs3 --steps 10 --warmup 3 --headline-only --no-cpu-baseline &&
+prof h512_serial XPS_OVERLAP_WGRAD=0 --workload configs3 --steps 10 --warmup 3 --headline-only --no-probes --no-cpu-baseline &&
+prof h512_fp32_serial XPS_OVERLAP_WGRAD=0 --workload configs3 --precision fp32 --steps 10 --warmup 3 --headline-only --no-probes --no-cpu-baseline &&
+prof cfg2_serial XPS_OVERLAP_WGRAD=0 --workload configs1 --steps 20 --warmup 5 --headline-only --no-probes --no-cpu-baseline &&
+prof h512_overlap XPS_OVERLAP_WGRAD=1 --workload configs3 --steps 10 --warmup 3 --headline-only --no-probes --no-cpu-baseline &&
 python3 $R/tools/timeline.py /tmp/h512_overlap_trace.csv > $O/h512_step_timeline.txt &&
 python3 $R/tools/prof_summary.py $O/h512_serial_kernel_stats.csv 33 "configs[3] shard, bf16x3, serial streams (XPS_OVERLAP_WGRAD=0), 20 pre-warm + 3 warm-up + 10 timed steps" > $O/h512_serial_summary.md &&
 python3 $R/tools/prof_summary.py $O/h512_fp32_serial_kernel_stats.csv 33 "configs[3] shard, fp32 MFMA mode (--precision fp32), serial streams, 20 pre-warm + 3 warm-up + 10 timed steps" > $O/h512_fp32_serial_summary.md &&
