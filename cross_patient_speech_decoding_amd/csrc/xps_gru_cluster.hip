@@ -199,6 +199,9 @@ __device__ inline void cl_dma4(const unsigned char* gsrc, unsigned l0, unsigned 
 // both reads of a fragment and regroup them before the first MFMA), as did a per-lane group permutation on the source side of the
 // DMA pieces.  The planes stay the default.
 __device__ inline unsigned cl_xslot(unsigned g) { return ((g & 1u) << 2) | ((g & 7u) >> 1); }
+#ifndef XPS_CL_BWD_LINEPLANAR
+#define XPS_CL_BWD_LINEPLANAR 0     // exchange rows of the 1-D BPTT kernel (bf16x3): 0 = hi plane | lo plane, 1 = line-planar (see its epilogue; measured slower)
+#endif
 #ifndef XPS_CL_FWD_PLANES
 #define XPS_CL_FWD_PLANES 1        // 0: the forward kernel's exchange rows as XPS_FMT_SPLIT4 groups (see above; A/B builds)
 #endif
@@ -946,11 +949,29 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             for (int g = 0; g < 3; ++g) {
                 const unsigned base = (chunk0 + g) * (unsigned)Cf::CHUNK_BYTES + rowoff;
                 if constexpr (BF) {
-                    // hi plane + lo plane of the row (XPS_FMT_SPLIT4 rows here cost 5-8 %: see XPS_CL_FWD_PLANES above)
                     bf16x4 sh, sl;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { __bf16 a, c; bf_split((*gsrc[g])[i], a, c); sh[i] = a; sl[i] = c; }
-                    if (fast) {
+                    if (XPS_CL_BWD_LINEPLANAR) {
+                        // LINE-PLANAR row (alternative, compile time): every 128-byte line holds the hi halves of its 32 k (64 B), then
+                        // their lo halves (64 B).  The two lanes of a unit octet swap one half (DPP) so that the even lane stores
+                        // hi[0..7] and the odd lane lo[0..7] as ONE 16-byte vector each: three stores per lane and round instead of
+                        // six, a member's 32 units of a gate = one FULL line per trial (the planes: two half lines), and a fragment
+                        // register is still one contiguous 16-byte read (no regrouping in the contraction waves).  Bit-identical,
+                        // all cluster tests green -- and SLOWER on one box, three interleaved runs each (tools/bench_gru.py with
+                        // XPS_LIB_OVERRIDE): BPTT launch 812 / 812 / 829 us against 780 / 778 / 766 us with the planes.  The third
+                        // exchange layout with 16-byte stores that loses 5-8 % in this kernel (XPS_CL_FWD_PLANES above).
+                        const bool odd = (guq & 1) != 0;
+                        const u32x2 mine_h = __builtin_bit_cast(u32x2, sh), mine_l = __builtin_bit_cast(u32x2, sl);
+                        const u32x2 give = odd ? mine_h : mine_l;
+                        u32x2 got;
+                        got[0] = (unsigned)__shfl_xor((int)give[0], 1);
+                        got[1] = (unsigned)__shfl_xor((int)give[1], 1);
+                        const u32x4 v = odd ? (u32x4){got[0], got[1], mine_l[0], mine_l[1]} : (u32x4){mine_h[0], mine_h[1], got[0], got[1]};
+                        const unsigned xo = base + ((unsigned)ju & ~31u) * 4u + (odd ? 64u : 0u) + (unsigned)(guq >> 1) * 16u;
+                        if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, xr, xo, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, xr, xo, 0, AUX_SC1);
+                    } else if (fast) {
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sh), xr, base + (unsigned)ju * 2u, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sl), xr, base + KP * 2 + (unsigned)ju * 2u, 0, 0);
                     } else {
@@ -1058,9 +1079,12 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                             // (two groups on gate waves 5-7 as well: 991 vs 992 us, no further gain)
                             // (gg == 0: the gate waves are busy with the gate math and move one group; otherwise they idle and move two)
                             if (has_next && (c & 3) == 0 && tt * 2 + (c >> 2) < (gg == 0 ? 3 : 2)) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
-                            const unsigned char* rp = tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
+                            // (planes: hi plane at the row, lo plane PS further; line-planar rows: k-half kh is its own piece, PS
+                            //  apart, and a line holds hi[32] | lo[32] -- the same bank pattern per instruction)
+                            const unsigned char* rp = XPS_CL_BWD_LINEPLANAR ? tb + (tt * 16 + n) * TS + kh * PS + c * 128 + kq * 16
+                                                                            : tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
                             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
-                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + PS);
+                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + (XPS_CL_BWD_LINEPLANAR ? 64 : PS));
                             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[gg][c], bh, acc[tt], 0, 0, 0);
                             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bl, acc[tt], 0, 0, 0);
                             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bh, acc[tt], 0, 0, 0);
