@@ -35,7 +35,7 @@ for prec in precs:
     for mode in modes:
         xf.set_gru_cluster_mode(mode)
         xf.check_gru_status()
-        f_tr = ev(lambda: xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True))
+        f_tr = ev(lambda: xf.gru_forward_training_form(gi, ws, bs, T, B, H, ndir))
         xf.check_gru_status()
         f_ev = ev(lambda: xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, False))
         y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
