@@ -302,14 +302,28 @@ def roofline_cluster(model, c, dev):
     b_hh = [rnn.bias_hh_l1.detach().contiguous(), rnn.bias_hh_l1_reverse.detach().contiguous()]
     gi = torch.randn(2, Tp, B, 3 * H, device=dev) * 0.5
     dy = torch.randn(Tp, B, 2 * H, device=dev) * 0.1
-    # forward: gi is written by the projection GEMM right in front of the launch in the step; the probe re-writes it (an HBM-rate
-    # copy, outside the event pair) before every timed launch.  (Round 3 timed back-to-back launches on one stale 503-MB gi: 615 us
-    # against 470-510 us for the same kernel inside the profiled step -- the VERDICT's "one of the two numbers is not measuring
-    # what the step runs": it was the probe.)
-    gi_src = gi.clone()
+    # forward: in the step gi is written by the layer's input-projection GEMM right in front of the launch, and the launch time depends
+    # on what ran before it (tools/probe_fwd_context.py, one box: 625 us back to back with itself on a stale gi -- what round 3's
+    # probe timed --, 516 us behind a copy into gi, 497 us behind the projection GEMM = the 496 us of the profiled step, 485 us behind
+    # a 1-GiB fill).  The probe therefore issues THAT GEMM (same operands' shapes and formats as functional.GRULayerFmtFn.forward)
+    # in front of every timed launch, outside the event pair.
+    import ctypes as C
+    from cross_patient_speech_decoding_amd._lib import call as _call, rowmap as _rowmap
+    In1 = 2 * H
+    w_ih = [rnn.weight_ih_l1.detach().contiguous(), rnn.weight_ih_l1_reverse.detach().contiguous()]
+    b_ih = [rnn.bias_ih_l1.detach().contiguous(), rnn.bias_ih_l1_reverse.detach().contiguous()]
+    x1 = torch.randn(Tp, B, In1, device=dev) * 0.5
+    sfmt = 1 if XF.split4_wanted(Tp, B, H, 2) else 0
+    if sfmt:
+        x1, w_ih = XF.split4(x1), [XF.split4(w) for w in w_ih]
+
+    def projection():
+        ra, rb, rc = _rowmap(In1, fmt=sfmt), _rowmap(In1, fmt=sfmt), _rowmap(3 * H)
+        _call('xps_gemm_nt_multi_f32', XF._ptr(x1), C.byref(ra), XF._ptr_array(w_ih), C.byref(rb), XF._ptr_array([gi[d] for d in range(2)]),
+              C.byref(rc), XF._ptr_array(b_ih), 2, Tp * B, 3 * H, In1, XF._stream())
     # (the launch form the step uses: in bf16x3 mode with the split4 image of y_ext as its exchange buffer -- it also writes those 184 MB,
     #  which `traffic` contains and the algorithmic bytes below do not)
-    t_f = _event_time(lambda: XF.gru_forward_training_form(gi, w_hh, b_hh, Tp, B, H, 2), iters=10, prepare=lambda: gi.copy_(gi_src))
+    t_f = _event_time(lambda: XF.gru_forward_training_form(gi, w_hh, b_hh, Tp, B, H, 2), iters=10, prepare=projection)
     y_ext, saved = XF.gru_forward_training_form(gi, w_hh, b_hh, Tp, B, H, 2)
     split = XF.split4_wanted(Tp, B, H, 2)
     t_b = _event_time(lambda: XF._gru_backward(dy, None, y_ext, saved, w_hh, Tp, B, H, 2, False, split4=split), iters=10)
