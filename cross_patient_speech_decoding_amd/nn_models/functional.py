@@ -741,7 +741,7 @@ class GRULayerFmtFn(torch.autograd.Function):
             if fmt and not w_fmt and skinny_dx_wanted(T * B, In, 3 * H):
                 # few input channels (configs[3] layer 0: In = 100): dx = dgi W_ih is bound by the read of dgi (503 MB), not by the
                 # matrix pipe -- W_ih as a zero-padded 256-column split4 image, so that the product takes ONE 256-wide tile per 256
-                # rows on the LDS-DMA loop (gemm_big_kernel<.., 5>: 213 -> ~120 us) instead of 64-row edge tiles
+                # rows on the LDS-DMA loop (gemm_big_kernel<.., 5>) instead of 64-row edge tiles; measured SLOWER (261 vs 213 us): opt-in, see skinny_dx_wanted
                 w_ih = [split4_pad(w, 256) for w in w_ih]
                 w_fmt, ldw = 1, 256
             else:
