@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256, (BF && MI == 1) ? XPS_BF_MI1_WAVES : XPS_GEMM_
 // tile's split + LDS stores and the previous tile's C stores spread over the k-steps of the current one, one barrier per tile;
 // same bits, 244 registers -- ran SLOWER (82-93 us): one accumulator chain per wave instead of two, twice the barriers per
 // byte.  Left for the next round: two independent wave teams per CU (anti-phase), or the pipeline with 64-row tiles for K <= 192.
+// Round 4, the C stores (the kernel writes 503 MB of gi for configs[3]'s layer 0 at 3.4 TB/s through 32 scalar stores per lane and
+// tile, each wave-instruction two FULL 128-byte lines): 16-byte stores from SWAPPED MFMA operands (a lane then holds four
+// consecutive columns of one row; 8 store instructions instead of 32; same bits) were built and measured -- every instruction
+// then touches 32 rows x 32 bytes, and the launches take 125-130 / 112-117 / 56 us instead of 85-92 / 43-45 / 28 us on the three
+// shapes above (configs[3] step + 0.3 ms): full lines per instruction matter more than the instruction count.  Not kept.
 template <int KT>
 __global__ __launch_bounds__(512, 1) void proj_ws_kernel(const float* __restrict__ A, long long lda, NtMulti pm, long long ldb, long long ldc,
                                                          int M, int N, int K, int nprob, int preA, int preB) {
