@@ -796,9 +796,15 @@ struct ClBwd {
 // the finished products over after g == 2 (xacc, double buffered by round parity); gate waves act once per round, during its
 // first sub-iteration: gate math of the PREVIOUS round (products from xacc, inputs requested one round earlier), exchange rows,
 // outputs, then the requests for THIS round's inputs; wave 4 also keeps the flags.
-template <int KSPLIT, bool BF>
+// XOUT (bf16x3 mode, split4 outputs, H == KP, no pad trials): the OUTPUTS are the exchange rows -- dgi's r and z columns and dghn of
+// step ps - 1 are exactly the gate gradients step ps contracts, and they are written as XPS_FMT_SPLIT4 groups anyway.  No exchange
+// ring, no exchange stores (six 8-byte stores per lane and round less, 0.5 GB of write-through traffic per launch less); the
+// operand images are moved from the rows of dgi / dghn (lanes of a piece in even / odd group order: cl_ximg_lane) and the
+// contraction waves regroup the halves of two groups per fragment, as the forward kernel's XIMG form does.
+template <int KSPLIT, bool BF, bool XOUT = false>
 __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     static_assert(KSPLIT == 2, "the cluster kernels cover 256 < H <= 512");
+    static_assert(!XOUT || BF, "outputs as exchange rows: bf16x3 mode only");
     using Cf = ClCfg<KSPLIT, BF, 3>;
     constexpr int KP = Cf::KP, TS = Cf::TS, PS = Cf::PS, TILE = Cf::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -838,15 +844,30 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xbuf);
     // (w: the contraction wave whose quarter of the pieces is meant; gate wave 4 + w moves the last group of wave w's quarter)
     const int dw = wave & 3;
+    // XOUT: rows of the step processed before (time index t_prev) in dgi (segments r, z: 3H elements per trial) / dghn (segment n)
+    // -- the trial stride (bytes) is folded into bit 0..: dgi rows lie 6 KB apart, dghn rows 2 KB; it travels in the low bits of
+    // nothing: dma_group recomputes it from the segment it is given
     auto dma_src = [&](int ps_, int r_, int g_) -> const unsigned char* {
+        if constexpr (XOUT) {
+            const int sp = T - 1 - (ps_ - 1);
+            const int tp = (dir == 0) ? sp : T - 1 - sp;
+            const long long row = ((long long)dir * T + tp) * B + m_base + 32 * r_ + 8 * dw;
+            const float* base = g_ < 2 ? p.dgi + row * 3 * H + g_ * H : p.dghn + row * H;
+            return reinterpret_cast<const unsigned char*>(base) + cl_ximg_lane(lane) * 16;
+        }
         const size_t chunk = (size_t)(((((ps_ - 1) & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r_) * 3 + g_);
         return xb + chunk * Cf::CHUNK_BYTES + (size_t)(dw * 16) * 1024 + lane * 16;
     };
-    auto dma_group = [&](const unsigned char* src, int buf, int grp) {
+    auto dma_group = [&](const unsigned char* src, int buf, int grp, int g_ = 0) {
         const int j = dw * 16 + grp * 4;
         const unsigned base = lds0 + (unsigned)(buf * TILE) + (unsigned)((j >> 1) * TS);
         const unsigned h = BF ? PS : 1024;
-        cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
+        if constexpr (XOUT) {
+            const long long st = (g_ < 2 ? 3LL : 1LL) * H * 4;           // bytes between the rows of two trials
+            cl_dma2x2(src + (2 * grp) * st, src + (2 * grp + 1) * st, base, base + h - 1024, base + TS, base + TS + h - 1024);
+        } else {
+            cl_dma4(src + grp * 4096, base, base + h - 1024, base + TS - 2048, base + TS + h - 3072);
+        }
     };
 
     struct EpiIn { f32x4 dy, rg, zg, ng, q, hp; u32x4 keep; };
@@ -942,7 +963,29 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
             danr[i] = live ? da * r_ : 0.f;
             keep[i] = dh * z_;
         }
-        if (kind == 1 || (kind == 0 && ps + 1 < p.ps_total)) {      // someone will contract these gradients
+        const bool contracted = kind == 1 || (kind == 0 && ps + 1 < p.ps_total);      // someone will contract these gradients
+        if (XOUT && contracted) {
+            // the outputs dgi (r, z) and dghn ARE the exchange rows: issued first (the counted wait in front of the hand-off barrier
+            // covers them), write-through unless the cluster sits on one XCD; dgi's n column and the running gradient follow below
+            const unsigned go_ = live ? (unsigned)(((((long long)dir * T + t) * B + b) * 3 * H + ju) * 4) : CL_OOB;
+            const unsigned no_ = live ? (unsigned)(((((long long)dir * T + t) * B + b) * H + ju) * 4) : CL_OOB;
+            const u32x4 xr_ = __builtin_bit_cast(u32x4, split4_pack(dar)), xz_ = __builtin_bit_cast(u32x4, split4_pack(daz)),
+                        xn_ = __builtin_bit_cast(u32x4, split4_pack(danr));
+            if (fast) {
+                __builtin_amdgcn_raw_buffer_store_b128(xr_, gr, go_, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(xz_, gr, live ? go_ + (unsigned)H * 4u : CL_OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(xn_, nr, no_, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(xr_, gr, go_, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(xz_, gr, live ? go_ + (unsigned)H * 4u : CL_OOB, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(xn_, nr, no_, 0, AUX_SC1);
+            }
+            CL_FENCE();
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, split4_pack(dan)), gr, live ? go_ + (unsigned)H * 8u : CL_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, keep), kr, live ? (unsigned)(((((long long)dir * p.CS + cm.member) * B + b) * 32 + (ju & 31)) * 4) : CL_OOB, 0, 0);
+            return 2;
+        }
+        if (!XOUT && contracted) {
             const unsigned chunk0 = (unsigned)((((ps & 1) * p.ndir + dir) * (p.Bp / 32) + (m_base / 32) + r) * 3);
             const unsigned rowoff = (unsigned)gtr * (unsigned)(KP * 4);
             const f32x4* gsrc[3] = {&dar, &daz, &danr};
@@ -1031,7 +1074,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
     if (wave < 4) {
         const unsigned char* src = dma_src(ps0, 0, 0);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) dma_group(src, q_begin & 1, g4);
+        for (int g4 = 0; g4 < 4; ++g4) dma_group(src, q_begin & 1, g4, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -1079,13 +1122,23 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                             // contraction wave ~1300 cycles of a 3400-cycle sub-iteration while the gate waves idled at the barrier)
                             // (two groups on gate waves 5-7 as well: 991 vs 992 us, no further gain)
                             // (gg == 0: the gate waves are busy with the gate math and move one group; otherwise they idle and move two)
-                            if (has_next && (c & 3) == 0 && tt * 2 + (c >> 2) < (gg == 0 ? 3 : 2)) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2));
+                            if (has_next && (c & 3) == 0 && tt * 2 + (c >> 2) < (gg == 0 ? 3 : 2)) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 2), g_n);
                             // (planes: hi plane at the row, lo plane PS further; line-planar rows: k-half kh is its own piece, PS
                             //  apart, and a line holds hi[32] | lo[32] -- the same bank pattern per instruction)
-                            const unsigned char* rp = XPS_CL_BWD_LINEPLANAR ? tb + (tt * 16 + n) * TS + kh * PS + c * 128 + kq * 16
-                                                                            : tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
-                            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rp);
-                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rp + (XPS_CL_BWD_LINEPLANAR ? 64 : PS));
+                            bf16x8 bh, bl;
+                            if constexpr (XOUT) {
+                                // split4 groups, even | odd per line (cl_ximg_lane): groups 2 kq and 2 kq + 1 of chunk c, halves regrouped
+                                const unsigned char* rp = tb + (tt * 16 + n) * TS + kh * PS + c * 128 + kq * 16;
+                                const bf16x8 ga = *reinterpret_cast<const bf16x8*>(rp);
+                                const bf16x8 gb = *reinterpret_cast<const bf16x8*>(rp + 64);
+                                bh = __builtin_shufflevector(ga, gb, 0, 1, 2, 3, 8, 9, 10, 11);
+                                bl = __builtin_shufflevector(ga, gb, 4, 5, 6, 7, 12, 13, 14, 15);
+                            } else {
+                                const unsigned char* rp = XPS_CL_BWD_LINEPLANAR ? tb + (tt * 16 + n) * TS + kh * PS + c * 128 + kq * 16
+                                                                                : tb + (tt * 16 + n) * TS + (kbase + 32 * c + 8 * kq) * 2;
+                                bh = *reinterpret_cast<const bf16x8*>(rp);
+                                bl = *reinterpret_cast<const bf16x8*>(rp + (XPS_CL_BWD_LINEPLANAR ? 64 : PS));
+                            }
                             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wl[gg][c], bh, acc[tt], 0, 0, 0);
                             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bl, acc[tt], 0, 0, 0);
                             acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.wh[gg][c], bh, acc[tt], 0, 0, 0);
@@ -1093,7 +1146,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
                     } else {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            if (has_next && (c & 7) == 0) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 3));
+                            if (has_next && (c & 7) == 0) dma_group(src, (q + 1) & 1, tt * 2 + (c >> 3), g_n);
                             const f32x4 a4 = *reinterpret_cast<const f32x4*>(tb + (tt * 16 + n) * TS + (kbase + 16 * c + 4 * kq) * 4);
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -1160,7 +1213,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
         if constexpr (BF) {
             // this wave's share of the next sub-iteration's operand: the fourth group of contraction wave (wave - 4)'s quarter,
             // first in the stream so that the counted wait covers it
-            dma_group(dma_src(ps, r, 1), (q0 + 1) & 1, 3);
+            dma_group(dma_src(ps, r, 1), (q0 + 1) & 1, 3, 1);
             CL_FENCE();
         }
         int younger = 0;                                       // operations issued after the exchange stores (see cl_wait_vmcnt)
@@ -1181,8 +1234,8 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
 #endif
         // ---------------- g == 1 ----------------
         if constexpr (BF) {
-            dma_group(dma_src(ps, r, 2), (q0 + 2) & 1, 2);
-            dma_group(dma_src(ps, r, 2), (q0 + 2) & 1, 3);
+            dma_group(dma_src(ps, r, 2), (q0 + 2) & 1, 2, 2);
+            dma_group(dma_src(ps, r, 2), (q0 + 2) & 1, 3, 2);
             CL_FENCE();
         }
         // flag of the round whose gate math ran above: its exchange rows were complete before the last barrier
@@ -1206,7 +1259,7 @@ __global__ __launch_bounds__(512, 2) void gru_cluster_bwd_kernel(ClBwd p) {
 #endif
         // ---------------- g == 2 ----------------
         if constexpr (BF) {
-            if (has_next) { dma_group(dma_src(ps_n, r_n, 0), (q0 + 3) & 1, 2); dma_group(dma_src(ps_n, r_n, 0), (q0 + 3) & 1, 3); }
+            if (has_next) { dma_group(dma_src(ps_n, r_n, 0), (q0 + 3) & 1, 2, 0); dma_group(dma_src(ps_n, r_n, 0), (q0 + 3) & 1, 3, 0); }
             CL_FENCE();
         }
         pend_ps = ps; pend_r = r;
@@ -1873,7 +1926,7 @@ struct ClDev {
     // [kernel kind: forward / 1-D BPTT / 2-D BPTT][fp32 / bf16x3]; the (kernel, LDS bytes) pair is part of the key: the 2-D BPTT
     // kernel has another LDS block and register count than the 1-D one.  Relaxed atomics: the autograd thread and
     // the main thread may both ask; either computes the same value.
-    std::atomic<int> resident[4][2];
+    std::atomic<int> resident[5][2];
     ClDev() { for (auto& k : resident) for (auto& v : k) v.store(-1, std::memory_order_relaxed); }
     unsigned* sticky = nullptr;
 };
@@ -1997,8 +2050,8 @@ bool cl_set_lds(K kernel, int bytes) {
 inline bool cl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // workgroups of `kernel` (512 threads, `lds` bytes) the current device holds at once; cached per device and kernel kind
-// (kind: 0 forward, 1 one-dimensional BPTT, 2 two-dimensional BPTT, 3 forward with the image exchange -- each kind is ONE (kernel, lds)
-// pair per precision)
+// (kind: 0 forward, 1 one-dimensional BPTT, 2 two-dimensional BPTT, 3 forward with the image exchange, 4 one-dimensional BPTT with its
+// outputs as exchange rows -- each kind is ONE (kernel, lds) pair per precision)
 template <typename K>
 int cl_resident(K kernel, int lds, int kind, int bf) {
     const int dev = cl_device();
@@ -2018,6 +2071,12 @@ int cl_resident(K kernel, int lds, int kind, int bf) {
 bool cl_ximg_enabled() {
     const char* e = getenv("XPS_GRU_XIMG");
     return !(e && e[0] == '0');
+}
+
+// XPS_GRU_XOUT=1: the 1-D BPTT kernel reads its exchange rows from its own outputs (A/B; read per call)
+bool cl_xout_enabled() {
+    const char* e = getenv("XPS_GRU_XOUT");
+    return e && e[0] == '1';
 }
 
 unsigned* cl_sticky() {
@@ -2203,6 +2262,8 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     p.xbuf_bytes = (unsigned)pl.xbuf_bwd;
     p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.Bp = pl.Bp; p.Mc = pl.Mc; p.NR = pl.NR; p.nblk = pl.nblk; p.CS = pl.CS;
     p.saved_mm = (H % 32 == 0) ? 1 : 0;
+    // outputs as exchange rows (gru_cluster_bwd_kernel<.., XOUT>): split4 outputs, rows of exactly KP elements, no pad trials
+    const bool xout = bf && split_out && H == pl.KP && pl.Bp == B && cl_xout_enabled();
     if (hipMemsetAsync(ws, 0, pl.flags_bytes, st) != hipSuccess) { xps_set_error("gru cluster backward: memset failed"); return XPS_E_HIP; }
     if (pl.CS * pl.U < pl.KP) {
         // gate-gradient columns no member owns (H far below KP) are contracted with zero weights: they must be finite
@@ -2213,7 +2274,7 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
     p.sticky = cl_sticky();
     auto launch = [&](auto kernel, int lds) -> bool {
         if (!cl_set_lds(kernel, lds)) return false;
-        const bool persistent = cl_mode() == 2 && pl.grid <= cl_resident(kernel, lds, 1, bf ? 1 : 0);
+        const bool persistent = cl_mode() == 2 && pl.grid <= cl_resident(kernel, lds, xout ? 4 : 1, bf ? 1 : 0);
         if (persistent) {
             p.ps_begin = 0; p.ps_end = ps_total; p.handoff = 1;
             hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), lds, st, p);
@@ -2227,7 +2288,8 @@ int xps_internal_gru_cluster_bwd(const float* dy, const float* dhn, const float*
         return true;
     };
     bool ok;
-    ok = bf ? launch(gru_cluster_bwd_kernel<2, true>, ClCfg<2, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<2, false>, ClCfg<2, false, 3>::LDS_BYTES);
+    ok = xout ? launch(gru_cluster_bwd_kernel<2, true, true>, ClCfg<2, true, 3>::LDS_BYTES)
+       : bf ? launch(gru_cluster_bwd_kernel<2, true>, ClCfg<2, true, 3>::LDS_BYTES) : launch(gru_cluster_bwd_kernel<2, false>, ClCfg<2, false, 3>::LDS_BYTES);
     if (!ok) { xps_set_error("gru cluster backward: cannot raise the dynamic LDS limit"); return XPS_E_HIP; }
     XPS_CHECK_LAUNCH();
     return XPS_OK;

@@ -40,7 +40,8 @@ for prec in precs:
         f_ev = ev(lambda: xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, False))
         y_ext, saved = xf._gru_forward(gi, ws, bs, None, T, B, H, ndir, True)
         xf.check_gru_status()
-        b_tr = ev(lambda: xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False))
+        sp4 = xf.split4_wanted(T, B, H, ndir)                     # (the output format the training step asks for)
+        b_tr = ev(lambda: xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False, split4=sp4))
         diag = ''
         xf.check_gru_status()
         by_f = 4 * ndir * T * B * (3 * H + H + 4 * H)

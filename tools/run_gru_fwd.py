@@ -15,6 +15,6 @@ if os.environ.get('GRID'):          # 1: the 4 x 4 BPTT grid
 for _ in range(5):
     y_ext, saved = xf.gru_forward_training_form(gi, ws, bs, T, B, H, ndir)       # (the form a training step launches)
     if os.environ.get('BWD'):
-        xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False)
+        xf._gru_backward(dy, None, y_ext, saved, ws, T, B, H, ndir, False, split4=xf.split4_wanted(T, B, H, ndir))   # (the output format of the step)
 torch.cuda.synchronize()
 xf.check_gru_status()
