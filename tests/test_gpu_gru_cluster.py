@@ -224,6 +224,36 @@ def test_persistent_under_concurrent_load(cluster_mode):
             assert torch.equal(p, q), f'repeat {rep}'
 
 
+@pytest.mark.parametrize('mode', ['persistent', 'steps'])
+@pytest.mark.parametrize('T,B,ndir,need_dh0', [(4, 512, 2, False), (3, 256, 1, True), (1, 2048, 2, True)])
+def test_bptt_with_outputs_as_exchange_rows_equals_the_ring_bitwise(T, B, ndir, need_dh0, mode, cluster_mode, monkeypatch):
+    """XPS_GRU_XOUT=1 (gru_cluster_bwd_kernel<.., XOUT>: the operand images of step ps are moved from the dgi / dghn rows step ps - 1
+    wrote, no exchange ring; H = 512, bf16x3, split4 outputs) gives the bits of the default kernel: dgi, dghn, dh0."""
+    xf = XF()
+    H = 512
+    old = lib().xps_get_gemm_precision()
+    lib().xps_set_gemm_precision(1)
+    try:
+        cluster_mode(mode)
+        g = torch.Generator().manual_seed(T * 7 + B)
+        gi = (torch.randn(ndir, T, B, 3 * H, generator=g) * 0.5).cuda()
+        w_hh = [(torch.randn(3 * H, H, generator=g) * H ** -0.5).cuda() for _ in range(ndir)]
+        b_hh = [(torch.randn(3 * H, generator=g) * 0.1).cuda() for _ in range(ndir)]
+        dy, dhn = (torch.randn(T, B, ndir * H, generator=g) * 0.1).cuda(), (torch.randn(ndir, B, H, generator=g) * 0.1).cuda()
+        y_ext, saved = xf._gru_forward(gi, w_hh, b_hh, None, T, B, H, ndir, True)
+        outs = []
+        for flag in ('0', '1'):
+            monkeypatch.setenv('XPS_GRU_XOUT', flag)
+            outs.append(xf._gru_backward(dy, dhn, y_ext, saved, w_hh, T, B, H, ndir, need_dh0, split4=True))
+        torch.cuda.synchronize()
+        xf.check_gru_status()
+        for a, b in zip(*outs):
+            if a is not None:
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    finally:
+        lib().xps_set_gemm_precision(old)
+
+
 def test_launch_form_change_between_forward_and_backward_is_refused(cluster_mode):
     """The saved gates are member-major on the cluster path and row-major off it: a backward under the other launch form would
     read them wrongly, so functional._gru_backward refuses (the forward stamps the buffer)."""
